@@ -1,0 +1,211 @@
+"""Drop-in nn.Module shells for the reference's two hot-path modules.
+
+    Backbone(num_layers, drop_ratio, mode)      pretrain/model_ir_se50.py:108-141
+    ir_se_50_512(weights_path)                  pretrain/model_ir_se50.py:143-154
+    RecNet(channel, shape, norm_type, relu_type) models/recnet.py:347-429
+
+Same constructor signatures, same forward signatures / return tuples and the SAME
+state_dict key set (402 / 121 entries), so se50.pth / FFRNet.pth style checkpoints and
+`net.load_state_dict(other.state_dict())` (models/trainer.py:98-113) work unchanged.
+The parameter tree below only HOLDS weights; all arithmetic of forward() runs in
+libffrnet_hip.so (hand-written gfx950 kernels) through ffrnet_amd.native.Engine.
+The packed / BN-folded device copy is a cache owned by the native handle and is
+rebuilt whenever a parameter or buffer changes (load_state_dict, .to(), in-place edit).
+
+Only the eval / label=None path exists natively (SURVEY.md 8b "mode semantics"):
+training-mode forward and the label branch raise -- there is no CPU or stock-torch
+fallback anywhere in this package.
+"""
+import torch
+import torch.nn as nn
+
+from .native import Engine
+from .synth import irse50_blocks
+
+
+def l2_norm(input, axis=1):
+    """pretrain/model_ir_se50.py:13-16 (host helper, no eps)."""
+    return input / torch.norm(input, 2, axis, True)
+
+
+# ---- parameter holders (names fixed by the state_dict key contract) ---------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError('ffrnet_amd: sub-modules only hold weights; call the top-level '
+                           'Backbone / RecNet, whose forward runs in the HIP library')
+
+
+class Flatten(_Holder):
+    pass
+
+
+class SEModule(_Holder):
+    def __init__(self, channels, reduction):
+        super().__init__()
+        self.fc1 = nn.Conv2d(channels, channels // reduction, 1, bias=False)
+        self.fc2 = nn.Conv2d(channels // reduction, channels, 1, bias=False)
+
+
+class bottleneck_IR_SE(_Holder):
+    def __init__(self, in_channel, depth, stride):
+        super().__init__()
+        if in_channel == depth:
+            self.shortcut_layer = nn.MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = nn.Sequential(
+                nn.Conv2d(in_channel, depth, (1, 1), stride, bias=False), nn.BatchNorm2d(depth))
+        self.res_layer = nn.Sequential(
+            nn.BatchNorm2d(in_channel),
+            nn.Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+            nn.PReLU(depth),
+            nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
+            nn.BatchNorm2d(depth),
+            SEModule(depth, 16))
+
+
+class _NativeModule(nn.Module):
+    """Shared cache logic: one Engine per device, reloaded when any tensor changed."""
+    _kind = None
+
+    def _engine(self, device):
+        sig = (device.index, tuple((id(t), t._version) for t in self.state_dict(keep_vars=True).values()))
+        cache = self.__dict__.setdefault('_native_cache', {})
+        ent = cache.get(device.index)
+        if ent is None or ent[0] != sig:
+            eng = ent[1] if ent is not None else Engine(device.index)
+            getattr(eng, 'load_' + self._kind)(self.state_dict())
+            cache[device.index] = (sig, eng)
+            ent = cache[device.index]
+        return ent[1]
+
+    def _require_native(self, x, what):
+        if self.training:
+            raise NotImplementedError(
+                'ffrnet_amd.%s: only the eval() forward is implemented natively (the reference '
+                'keeps the encoder in eval and verifies with recnet.eval(), models/trainer.py:75-79); '
+                'call .eval() first' % what)
+        if not (torch.is_tensor(x) and x.is_cuda):
+            raise RuntimeError('ffrnet_amd.%s: input must be a ROCm device tensor; this package has '
+                               'no CPU path' % what)
+        if x.dtype != torch.float32:
+            raise RuntimeError('ffrnet_amd.%s: input must be float32' % what)
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == '_native_cache':
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+
+class Backbone(_NativeModule):
+    _kind = 'encoder'
+
+    def __init__(self, num_layers, drop_ratio, mode='ir'):
+        super().__init__()
+        assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
+        assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
+        if num_layers != 50 or mode != 'ir_se':
+            raise NotImplementedError('ffrnet_amd: only Backbone(50, *, "ir_se") (IR-SE50, the one '
+                                      'the reference instantiates, model_ir_se50.py:150) is native')
+        self.input_layer = nn.Sequential(nn.Conv2d(3, 64, (3, 3), 1, 1, bias=False),
+                                         nn.BatchNorm2d(64), nn.PReLU(64))
+        self.output_layer = nn.Sequential(nn.BatchNorm2d(512), nn.Dropout(drop_ratio), Flatten(),
+                                          nn.Linear(512 * 7 * 7, 512), nn.BatchNorm1d(512))
+        self.bn = nn.BatchNorm2d(512)
+        self.body = nn.Sequential(*[bottleneck_IR_SE(c, d, s) for c, d, s in irse50_blocks()])
+
+    def forward(self, x):
+        """-> (featmap[N,512,7,7], l2_norm(feat)[N,512]); model_ir_se50.py:136-141."""
+        self._require_native(x, 'Backbone')
+        return self._engine(x.device).encoder_forward(x)
+
+
+def ir_se_50_512(weights_path='./pretrain/se50.pth', **kwargs):
+    """model_ir_se50.py:143-154."""
+    model = Backbone(num_layers=50, drop_ratio=0.6, mode='ir_se')
+    if weights_path:
+        model.load_state_dict(torch.load(weights_path, map_location='cpu'))
+    return model
+
+
+class ReluLayer(_Holder):
+    def __init__(self, channels, relu_type='relu'):
+        super().__init__()
+        if relu_type.lower() != 'prelu':
+            raise NotImplementedError('ffrnet_amd: only relu_type="prelu" is native')
+        self.func = nn.PReLU(channels)
+
+
+class NormLayer(_Holder):
+    def __init__(self, channels, norm_type='bn'):
+        super().__init__()
+        if norm_type.lower() != 'bn':
+            raise NotImplementedError('ffrnet_amd: only norm_type="bn" is native')
+        self.norm = nn.BatchNorm2d(channels)
+
+
+class ConvLayer(_Holder):
+    """models/recnet.py:52-85 with norm 'bn' (=> conv bias=False, :57), relu 'prelu'."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, norm_type='bn', relu_type='prelu'):
+        super().__init__()
+        self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size, 1, bias=False)
+        self.relu = ReluLayer(out_channels, relu_type)
+        self.norm = NormLayer(out_channels, norm_type)
+
+
+class ResidualBlock(_Holder):
+    def __init__(self, inplanes, planes, kernel_size=3, norm_type='bn', relu_type='prelu'):
+        super().__init__()
+        self.conv1 = ConvLayer(inplanes, planes, kernel_size, norm_type, relu_type)
+        self.conv2 = ConvLayer(planes, planes, kernel_size, norm_type, relu_type)
+
+
+class AddMarginProduct(_Holder):
+    """Weight holder of the training-only CosFace head (models/recnet.py:238-270)."""
+
+    def __init__(self, in_features, out_features=10575, s=30.0, m=0.40):
+        super().__init__()
+        self.in_features, self.out_features, self.s, self.m = in_features, out_features, s, m
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class RecNet(_NativeModule):
+    _kind = 'recnet'
+
+    def __init__(self, channel=512, shape=7, norm_type='bn', relu_type='prelu'):
+        super().__init__()
+        if channel != 512 or shape != 7:
+            raise NotImplementedError('ffrnet_amd: RecNet is native for channel=512, shape=7 only')
+        self.channel, self.shape = channel, shape
+        a = dict(norm_type=norm_type, relu_type=relu_type)
+        s2 = shape ** 2
+        self.Conv4Space = nn.Sequential(
+            ConvLayer(channel + s2, 256, **a), ResidualBlock(256, 256, **a),
+            ConvLayer(256, 128, **a), ResidualBlock(128, 128, **a),
+            ConvLayer(128, s2, **a), ResidualBlock(s2, s2, **a), nn.Sigmoid())
+        self.Conv4Channel = nn.Sequential(
+            nn.Linear(channel + s2, 32), ReluLayer(512, 'prelu'), nn.Linear(32, channel),
+            nn.Linear(channel, 32), ReluLayer(512, 'prelu'), nn.Linear(32, channel),
+            nn.Linear(channel, 32), ReluLayer(512, 'prelu'), nn.Linear(32, channel),
+            nn.Sigmoid())
+        self.ChannelFlipMerge = nn.Sequential(ConvLayer(channel * 2, channel, **a),
+                                              ResidualBlock(channel, channel, **a))
+        self.Conv4Merge = nn.Sequential(ConvLayer(channel * 3, channel, **a),
+                                        ResidualBlock(channel, channel, **a))
+        self.pool5_7x7 = nn.AvgPool2d(kernel_size=[7, 7], stride=[1, 1], padding=0)
+        self.classifier = AddMarginProduct(channel)
+
+    def forward(self, input, label=None):
+        """label=None -> (f_new[N,512], feat_new[N,512,7,7]); models/recnet.py:398-426."""
+        if label is not None:
+            raise NotImplementedError('ffrnet_amd.RecNet: the label branch (recnet.py:427-429) is '
+                                      'the training path and is not implemented natively')
+        self._require_native(input, 'RecNet')
+        return self._engine(input.device).recnet_forward(input)

@@ -1,0 +1,293 @@
+"""ctypes binding of libffrnet_hip.so (include/ffrnet.h).
+
+PyTorch is used for device memory and streams only: tensors are handed over as raw
+device pointers (`tensor.data_ptr()`) and launches go to torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KCLASS_NAMES = ['conv_igemm', 'stem', 'se', 'combine', 'head', 'selfsim', 'channel',
+                'space', 'layout', 'score']
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.c_void_p), ('ndim', C.c_int32),
+                ('shape', C.c_int64 * 4)]
+
+
+class KClassStat(C.Structure):
+    _fields_ = [('launches', C.c_int64), ('ms', C.c_double), ('flops', C.c_double),
+                ('bytes', C.c_double)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int),
+                ('in_pitch', C.c_int), ('cin_pad', C.c_int),
+                ('w', C.c_void_p), ('bias', C.c_void_p), ('slope', C.c_void_p),
+                ('resid', C.c_void_p), ('res_pitch', C.c_int),
+                ('out', C.c_void_p), ('out_pitch', C.c_int), ('out_coff', C.c_int),
+                ('cout_store', C.c_int), ('cout_pad', C.c_int),
+                ('R', C.c_int), ('S', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
+                ('pad_mode', C.c_int), ('border_bias', C.c_int), ('flags', C.c_int),
+                ('tile', C.c_int), ('splitk', C.c_int)]
+
+
+def lib_path():
+    return os.path.join(_HERE, 'libffrnet_hip.so')
+
+
+# every symbol include/ffrnet.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ('ffr_create', C.c_int, [C.POINTER(_P), C.c_int]),
+    ('ffr_destroy', None, [_P]),
+    ('ffr_last_error', C.c_char_p, [_P]),
+    ('ffr_version', C.c_char_p, []),
+    ('ffr_load_encoder', C.c_int, [_P, C.POINTER(TensorDesc), C.c_int]),
+    ('ffr_load_recnet', C.c_int, [_P, C.POINTER(TensorDesc), C.c_int]),
+    ('ffr_encoder_forward', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    ('ffr_recnet_forward', C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    ('ffr_embed', C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    ('ffr_cosine_scores', C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    ('ffr_workspace_bytes', C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
+    ('ffr_reserve', C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    ('ffr_profile_enable', C.c_int, [_P, C.c_int]),
+    ('ffr_profile_read', C.c_int, [_P, C.POINTER(KClassStat)]),
+    ('ffr_op_conv', C.c_int, [_P, C.POINTER(ConvDesc), _P]),
+    ('ffr_encoder_trunk_nhwc', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    ('ffr_recnet_debug', C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+]
+
+
+def load_library():
+    """dlopen the in-tree library once; no fallback of any kind."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            'ffrnet_amd: %s not found -- build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the library lacks a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _check_dev(t, name, shape_tail=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('ffrnet_amd: %s is on %s; the native HIP path needs a ROCm device '
+                           'tensor (there is no CPU fallback)' % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError('ffrnet_amd: %s must be float32, got %s' % (name, t.dtype))
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise RuntimeError('ffrnet_amd: %s expected shape [N,%s], got %s'
+                           % (name, ','.join(map(str, shape_tail)), list(t.shape)))
+
+
+class Engine(object):
+    """One native handle on one ROCm device: packed weights + workspace arena."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.device = torch.device('cuda', device if isinstance(device, int) else
+                                   (device.index or 0))
+        self._h = C.c_void_p(0)
+        self._ck(self.lib.ffr_create(C.byref(self._h), self.device.index), create=True)
+        self.has_encoder = False
+        self.has_recnet = False
+
+    # -- plumbing -------------------------------------------------------------
+    def _ck(self, rc, create=False):
+        if rc != 0:
+            msg = self.lib.ffr_last_error(None if create else self._h)
+            raise RuntimeError('ffrnet native error %d: %s' % (rc, (msg or b'?').decode()))
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self.lib.ffr_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _descs(sd):
+        keep, items = [], []
+        for k, v in sd.items():
+            if not torch.is_tensor(v) or not v.is_floating_point():
+                continue
+            t = v.detach().to('cpu', torch.float32).contiguous()
+            if t.dim() < 1 or t.dim() > 4:
+                continue
+            keep.append(t)
+            d = TensorDesc()
+            d.name = k.encode()
+            d.data = t.data_ptr()
+            d.ndim = t.dim()
+            for i, s in enumerate(t.shape):
+                d.shape[i] = s
+            items.append(d)
+        arr = (TensorDesc * len(items))(*items)
+        return arr, len(items), keep
+
+    # -- weights --------------------------------------------------------------
+    def load_encoder(self, state_dict):
+        arr, n, keep = self._descs(state_dict)
+        self._ck(self.lib.ffr_load_encoder(self._h, arr, n))
+        self.has_encoder = True
+
+    def load_recnet(self, state_dict):
+        arr, n, keep = self._descs(state_dict)
+        self._ck(self.lib.ffr_load_recnet(self._h, arr, n))
+        self.has_recnet = True
+
+    # -- forward --------------------------------------------------------------
+    def encoder_forward(self, x, want_f=True, want_featmap=True):
+        _check_dev(x, 'x')
+        if x.dim() != 4 or x.size(1) != 3:
+            raise RuntimeError('ffrnet_amd: encoder input must be [N,3,H,W], got %s' % list(x.shape))
+        x = x.contiguous()
+        n, _, h, w = x.shape
+        if h % 16 or w % 16:
+            raise RuntimeError('ffrnet_amd: H and W must be multiples of 16, got %dx%d' % (h, w))
+        if want_f and (h, w) != (112, 112):
+            # same failure as the reference: Linear(512*7*7, 512), model_ir_se50.py:124
+            raise RuntimeError('mat1 and mat2 shapes cannot be multiplied (%dx%d and 25088x512)'
+                               % (n, 512 * (h // 16) * (w // 16)))
+        fm = torch.empty((n, 512, h // 16, w // 16), device=x.device, dtype=torch.float32) \
+            if want_featmap else None
+        f = torch.empty((n, 512), device=x.device, dtype=torch.float32) if want_f else None
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_encoder_forward(self._h, _ptr(x), n, h, w, _ptr(fm), _ptr(f),
+                                                  self._stream()))
+        return fm, f
+
+    def recnet_forward(self, featmap, want_feat_new=True):
+        _check_dev(featmap, 'input')
+        if featmap.dim() != 4 or tuple(featmap.shape[1:]) != (512, 7, 7):
+            c = featmap.size(1) + featmap.size(2) * featmap.size(3) if featmap.dim() == 4 else -1
+            # the reference fails in Conv4Space's first conv (models/recnet.py:363)
+            raise RuntimeError('RecNet expects input [N,512,7,7] (561 channels after the '
+                               'self-similarity concat), got %s (%d channels)'
+                               % (list(featmap.shape), c))
+        featmap = featmap.contiguous()
+        n = featmap.size(0)
+        f_new = torch.empty((n, 512), device=featmap.device, dtype=torch.float32)
+        feat_new = torch.empty((n, 512, 7, 7), device=featmap.device, dtype=torch.float32) \
+            if want_feat_new else None
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_recnet_forward(self._h, _ptr(featmap), n, _ptr(f_new),
+                                                 _ptr(feat_new), self._stream()))
+        return f_new, feat_new
+
+    def embed(self, x, want_f=True, out=None):
+        """x[N,3,112,112] -> (f_new[N,512], f[N,512]); `out` = preallocated (f_new, f)."""
+        _check_dev(x, 'x', (3, 112, 112))
+        x = x.contiguous()
+        n = x.size(0)
+        if out is not None:
+            f_new, f = out
+        else:
+            f_new = torch.empty((n, 512), device=x.device, dtype=torch.float32)
+            f = torch.empty((n, 512), device=x.device, dtype=torch.float32) if want_f else None
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_embed(self._h, _ptr(x), n, _ptr(f_new), _ptr(f), self._stream()))
+        return f_new, f
+
+    def cosine_scores(self, a, b):
+        _check_dev(a, 'a')
+        _check_dev(b, 'b')
+        if a.shape != b.shape or a.dim() != 2:
+            raise RuntimeError('cosine_scores: a and b must both be [n,dim]')
+        a, b = a.contiguous(), b.contiguous()
+        s = torch.empty((a.size(0),), device=a.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_cosine_scores(self._h, _ptr(a), _ptr(b), a.size(0), a.size(1),
+                                                _ptr(s), self._stream()))
+        return s
+
+    # -- arena / measurement --------------------------------------------------
+    def workspace_bytes(self, n, h=112, w=112):
+        return int(self.lib.ffr_workspace_bytes(self._h, n, h, w))
+
+    def reserve(self, n, h=112, w=112):
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_reserve(self._h, n, h, w))
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.ffr_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        arr = (KClassStat * len(KCLASS_NAMES))()
+        self._ck(self.lib.ffr_profile_read(self._h, arr))
+        return {KCLASS_NAMES[i]: dict(launches=int(arr[i].launches), ms=arr[i].ms,
+                                      flops=arr[i].flops, bytes=arr[i].bytes)
+                for i in range(len(KCLASS_NAMES))}
+
+    # -- test hooks -----------------------------------------------------------
+    def op_conv(self, **kw):
+        d = ConvDesc()
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                v = v.data_ptr()
+            elif v is None:
+                v = 0 if k not in ('x', 'w', 'bias', 'slope', 'resid', 'out') else None
+            setattr(d, k, v)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_op_conv(self._h, C.byref(d), self._stream()))
+
+    def encoder_trunk_nhwc(self, x, n_blocks):
+        _check_dev(x, 'x')
+        x = x.contiguous()
+        n, _, h, w = x.shape
+        chans, div = 64, 1
+        from .synth import irse50_blocks
+        for cin, depth, stride in irse50_blocks()[:n_blocks]:
+            chans, div = depth, div * stride
+        out = torch.empty((n, h // div, w // div, chans), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_encoder_trunk_nhwc(self._h, _ptr(x), n, h, w, n_blocks,
+                                                     _ptr(out), self._stream()))
+        return out
+
+    def recnet_debug(self, featmap):
+        _check_dev(featmap, 'input', (512, 7, 7))
+        featmap = featmap.contiguous()
+        n, dev = featmap.size(0), featmap.device
+        o = dict(ss_space=torch.empty((n, 49, 49), device=dev),
+                 M_space=torch.empty((n, 49, 49), device=dev),
+                 feat_space=torch.empty((n, 512, 7, 7), device=dev),
+                 feat_channel_raw=torch.empty((n, 512, 7, 7), device=dev),
+                 feat_channel=torch.empty((n, 512, 7, 7), device=dev))
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_recnet_debug(
+                self._h, _ptr(featmap), n, _ptr(o['ss_space']), _ptr(o['M_space']),
+                _ptr(o['feat_space']), _ptr(o['feat_channel_raw']), _ptr(o['feat_channel']),
+                self._stream()))
+        return o

@@ -1,0 +1,12 @@
+"""Import shim: the package directory is `ffr-net_amd/` (not a valid identifier), so
+`import ffrnet_amd` loads that directory as the package `ffrnet_amd`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ffr-net_amd')
+_spec = importlib.util.spec_from_file_location(
+    'ffrnet_amd', os.path.join(_dir, '__init__.py'), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules['ffrnet_amd'] = _mod
+_spec.loader.exec_module(_mod)

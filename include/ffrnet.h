@@ -1,0 +1,165 @@
+/*
+ * ffrnet.h -- C ABI of the MI355X-native FFR-Net embedding path (libffrnet_hip.so).
+ *
+ * The reference (haoosz/FFR-Net) has no FFI layer: its hot path is two Python
+ * nn.Module calls.  This header is the boundary a binding (ctypes, cgo, JNI ...)
+ * uses instead; each entry point names the reference code it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross the boundary;
+ *  - every function returns FFR_OK (0) or a negative ffr_status; nothing throws;
+ *    ffr_last_error() gives the text of the last failure on that handle;
+ *  - "device pointer" = HIP device memory of the handle's device; activations are
+ *    fp32; 4-D tensors at the boundary are NCHW contiguous (the reference's layout),
+ *    the NHWC layout used inside never leaves the library;
+ *  - launches are asynchronous on the hipStream_t passed as `void* stream`
+ *    (NULL = the default stream); no hidden device synchronisation;
+ *  - one handle per device; a handle is not thread safe.
+ */
+#ifndef FFRNET_H
+#define FFRNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ffr_handle ffr_handle;
+
+typedef enum {
+    FFR_OK = 0,
+    FFR_ERR_ARG = -1,        /* bad argument (null pointer, bad shape, N <= 0 ...)   */
+    FFR_ERR_STATE = -2,      /* weights not loaded yet                                */
+    FFR_ERR_KEY = -3,        /* a state_dict entry is missing or has the wrong shape  */
+    FFR_ERR_HIP = -4,        /* a HIP runtime call failed                             */
+    FFR_ERR_NOMEM = -5,      /* device allocation failed                              */
+    FFR_ERR_UNSUPPORTED = -6 /* shape the native path does not implement              */
+} ffr_status;
+
+/* One named fp32 tensor of a PyTorch state_dict, in HOST memory, C-contiguous.
+ * Integer entries (num_batches_tracked) are simply not passed.                     */
+typedef struct {
+    const char*  name;      /* e.g. "body.3.res_layer.1.weight"                      */
+    const float* data;
+    int32_t      ndim;      /* 1..4                                                   */
+    int64_t      shape[4];
+} ffr_tensor_desc;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int  ffr_create(ffr_handle** out, int device);
+void ffr_destroy(ffr_handle* h);
+const char* ffr_last_error(const ffr_handle* h);      /* h may be NULL: global text  */
+const char* ffr_version(void);
+
+/* ---- weights ---------------------------------------------------------------------
+ * Replaces Backbone.load_state_dict / RecNet.load_state_dict as used by
+ * pretrain/model_ir_se50.py:151-153 and models/trainer.py:98-113,201-214.
+ * Eval-mode BatchNorm is folded, weights are re-packed [Cout][R][S][Cin] for the
+ * NHWC implicit-GEMM kernels and uploaded; the caller keeps ownership of `t`.
+ * Encoder = IR-SE50 (Backbone(50, drop, 'ir_se')): 302 fp32 entries.
+ * RecNet  = RecNet(512, 7, 'bn', 'prelu'): 106 fp32 entries; "classifier.weight"
+ * (training-only head, models/recnet.py:396) is ignored if present.               */
+int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n);
+int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n);
+
+/* ---- forward ---------------------------------------------------------------------
+ * Backbone.forward, pretrain/model_ir_se50.py:136-141:
+ *   x[N,3,H,W] -> featmap[N,512,H/16,W/16] (after Backbone.bn) and f[N,512]
+ *   (output_layer + l2_norm).  f needs H=W=112 (Linear(512*7*7,512), :124); with any
+ *   other size pass f = NULL to get the trunk only (e.g. 112x96 -> [N,512,7,6]).
+ *   featmap or f may be NULL when not wanted.                                        */
+int ffr_encoder_forward(ffr_handle* h, const float* x_nchw, int N, int H, int W,
+                        float* featmap_nchw, float* f, void* stream);
+
+/* RecNet.forward(input, label=None), models/recnet.py:398-426:
+ *   featmap[N,512,7,7] -> f_new[N,512], feat_new[N,512,7,7] (either may be NULL).    */
+int ffr_recnet_forward(ffr_handle* h, const float* featmap_nchw, int N,
+                       float* f_new, float* feat_new_nchw, void* stream);
+
+/* encoder + recnet back to back as lfw/lfw_eval.py:240-244 calls them, without the
+ * NCHW round trip of featmap: x[N,3,112,112] -> f_new[N,512], f[N,512] (f may be NULL) */
+int ffr_embed(ffr_handle* h, const float* x_nchw, int N,
+              float* f_new, float* f, void* stream);
+
+/* cosine score of lfw/lfw_eval.py:246,248:  sum(a*b) / (|a|*|b| + 1e-8), per row.
+ * a, b [n,dim] device fp32 -> score[n] device fp32.                                 */
+int ffr_cosine_scores(ffr_handle* h, const float* a, const float* b, int n, int dim,
+                      float* score, void* stream);
+
+/* Device workspace the handle holds / would need for batch N (bytes).  The arena
+ * grows on the first call with a larger N (hipMalloc, outside any timed loop) and
+ * is reused afterwards; ffr_reserve() grows it ahead of time.                       */
+size_t ffr_workspace_bytes(const ffr_handle* h, int N, int H, int W);
+int    ffr_reserve(ffr_handle* h, int N, int H, int W);
+
+/* ---- measurement -----------------------------------------------------------------
+ * Per-kernel-class device timing with hipEvents recorded on the launch stream
+ * around every launch (bench.py roofline leg; off by default, adds a few us/launch).
+ * Classes: see FFR_KC_*.  ffr_profile_read() synchronises the recorded events and
+ * returns, per class, the number of launches, the summed device time in ms and the
+ * algorithmic FLOPs (2*MACs) and bytes (compulsory in+out+weights) of those launches,
+ * then clears the log.                                                              */
+enum {
+    FFR_KC_CONV_IGEMM = 0,  /* fp32-MFMA implicit-GEMM conv / FC (the dominant kernel) */
+    FFR_KC_STEM = 1,
+    FFR_KC_SE = 2,
+    FFR_KC_COMBINE = 3,
+    FFR_KC_HEAD = 4,
+    FFR_KC_SELFSIM = 5,
+    FFR_KC_CHANNEL = 6,
+    FFR_KC_SPACE = 7,
+    FFR_KC_LAYOUT = 8,
+    FFR_KC_SCORE = 9,
+    FFR_KC_COUNT = 10
+};
+typedef struct {
+    int64_t launches;
+    double  ms;
+    double  flops;
+    double  bytes;
+} ffr_kclass_stat;
+int ffr_profile_enable(ffr_handle* h, int on);
+int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out /* [FFR_KC_COUNT] */);
+
+/* ---- single operators (parity tests drive the kernels one at a time) -------------
+ * Implicit-GEMM convolution on NHWC fp32, the kernel behind every 3x3 / 1x1 conv of
+ * pretrain/model_ir_se50.py:63,67,69 and models/recnet.py:65,82.
+ *   x      [N,H,W,in_pitch]  (channels [0,cin_pad) are read; cin_pad % 32 == 0)
+ *   w      [cout_pad][R*S*cin_pad]  packed (r,s,ci), cout_pad % 64 == 0
+ *   bias   [n_cls][cout_pad], n_cls = 1, or 9 border classes when border_bias != 0
+ *   slope  [cout_pad] PReLU slopes or NULL
+ *   resid  [N,Ho,Wo,res_pitch] added after the activation, or NULL
+ *   out    [N,Ho,Wo,out_pitch], channels [out_coff, out_coff+cout_store) written
+ *   pad_mode 0 = zero, 1 = reflect;  flags bit0 = sigmoid at the end
+ *   tile   0 = heuristic, else 1..4 = forced tile config;  splitk 0 = heuristic      */
+typedef struct {
+    const float* x; int N, H, W, in_pitch, cin_pad;
+    const float* w; const float* bias; const float* slope;
+    const float* resid; int res_pitch;
+    float* out; int out_pitch, out_coff, cout_store, cout_pad;
+    int R, S, stride, pad, pad_mode, border_bias, flags;
+    int tile, splitk;
+} ffr_conv_desc;
+int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream);
+
+/* Encoder trunk only, stopping after `n_blocks` bottlenecks (0 = stem only,
+ * 24 = whole body, before Backbone.bn); writes the NHWC activation.  Test hook for
+ * the per-stage goldens.                                                            */
+int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x_nchw, int N, int H, int W,
+                           int n_blocks, float* out_nhwc, void* stream);
+
+/* RecNet internals for image-level goldens: any pointer may be NULL.
+ *   ss_space[N,49,49] M_space[N,49,49] M_channel is not materialised (fused);
+ *   feat_space[N,512,7,7] feat_channel_raw[N,512,7,7] (before ChannelFlipMerge)
+ *   feat_channel[N,512,7,7] (after ChannelFlipMerge), all NCHW.                     */
+int ffr_recnet_debug(ffr_handle* h, const float* featmap_nchw, int N,
+                     float* ss_space, float* M_space, float* feat_space,
+                     float* feat_channel_raw, float* feat_channel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFRNET_H */
