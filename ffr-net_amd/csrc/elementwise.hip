@@ -1,0 +1,323 @@
+// Trunk kernels that are not GEMMs: stem conv, squeeze-excitation, residual combine,
+// head finish, layout changes, cosine score.  All HBM/latency bound; 64-wide waves,
+// 16-byte accesses, wave-level shuffles for the reductions.
+#include "ffr_kernels.h"
+
+namespace ffr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Stem: Conv3x3(3->64, pad 1, no bias) + BN + PReLU   (pretrain/model_ir_se50.py:118-120)
+// Block = 256 threads = 16 channel quads x 16 pixel groups; 64 pixels per step, 4 pixels
+// per thread; the 4x27 weights of a thread's channel quad stay in registers, the 27-tap
+// patches of the 64 pixels are staged in LDS ([pix][28]) and read as 7 b128 per pixel.
+// ---------------------------------------------------------------------------------------
+#define STEM_PIX 64
+#define STEM_STEPS 8
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
+                                             const float* __restrict__ bias, const float* __restrict__ slope,
+                                             float* __restrict__ out, int N, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float patch[STEM_PIX * 28];
+    const int tid = threadIdx.x;
+    const int cg = tid & 15, pg = tid >> 4;
+    const int HW = H * W;
+    const long long total = (long long)N * HW;
+    f32x4 wr[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const f32x4*>(w + k * 64 + cg * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + cg * 4);
+    const f32x4 sl = *reinterpret_cast<const f32x4*>(slope + cg * 4);
+
+    for (int step = 0; step < STEM_STEPS; ++step) {
+        const long long p0 = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX;
+        if (p0 >= total) break;
+        __syncthreads();
+        // fill: element e = pix*28 + k, k = (ci*3 + r)*3 + s   (k == 27 is padding)
+        for (int e = tid; e < STEM_PIX * 28; e += 256) {
+            const int pix = e / 28, k = e - pix * 28;
+            float v = 0.f;
+            const long long p = p0 + pix;
+            if (k < 27 && p < total) {
+                const int n = (int)(p / HW);
+                const int rem = (int)(p - (long long)n * HW);
+                const int h = rem / W, wq = rem - h * W;
+                const int ci = k / 9, r = (k - ci * 9) / 3, s = k - ci * 9 - r * 3;
+                const int hi = h + r - 1, wi = wq + s - 1;
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    v = x[((long long)(n * 3 + ci) * H + hi) * W + wi];
+            }
+            patch[e] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pix = pg * 4 + q;
+            const long long p = p0 + pix;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const f32x4* pp = reinterpret_cast<const f32x4*>(patch + pix * 28);
+#pragma unroll
+            for (int k4 = 0; k4 < 7; ++k4) {
+                const f32x4 v = pp[k4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k4 * 4 + e;
+                    if (k < 27) acc += v[e] * wr[k];
+                }
+            }
+            acc += b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] >= 0.f ? acc[e] : acc[e] * sl[e];
+            if (p < total) *reinterpret_cast<f32x4*>(out + p * 64 + cg * 4) = acc;
+        }
+    }
+}
+
+hipError_t launch_stem(const float* x, const float* w, const float* bias, const float* slope, float* out,
+                       int N, int H, int W, hipStream_t stream) {
+    const long long total = (long long)N * H * W;
+    const long long per_block = (long long)STEM_PIX * STEM_STEPS;
+    const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
+    hipLaunchKernelGGL(k_stem, dim3(blocks), dim3(256), 0, stream, x, w, bias, slope, out, N, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// SEModule (pretrain/model_ir_se50.py:29-36), one block per image:
+//   mean over HW -> fc1 (C -> C/16) -> ReLU -> fc2 (C/16 -> C) -> sigmoid -> scale[n][c]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_se(const float* __restrict__ res, int HW, int C,
+                                           const float* __restrict__ fc1, const float* __restrict__ fc2,
+                                           float* __restrict__ scale) {
+    __shared__ __attribute__((aligned(16))) float s_part[1024];   // rows_par x C = 1024 for every C in {64..512}
+    __shared__ float s_mean[512];
+    __shared__ float s_hid[32];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const int cq = C >> 2;                 // float4 lanes per row: 16..128
+    const int rows_par = 256 / cq;         // rows processed in parallel: 16..2
+    const int lane_c = tid % cq, rgrp = tid / cq;
+    const float* base = res + (size_t)n * HW * C;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = rgrp; r < HW; r += rows_par)
+        acc += *reinterpret_cast<const f32x4*>(base + (size_t)r * C + lane_c * 4);
+    *reinterpret_cast<f32x4*>(s_part + rgrp * C + lane_c * 4) = acc;
+    __syncthreads();
+    const float inv = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < rows_par; ++g) s += s_part[g * C + c];
+        s_mean[c] = s * inv;
+    }
+    __syncthreads();
+    const int hid = C >> 4;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int j = wave; j < hid; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += fc1[j * C + c] * s_mean[c];
+        s = wave_sum(s);
+        if (lane == 0) s_hid[j] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < hid; ++j) s += fc2[c * hid + j] * s_hid[j];
+        scale[(size_t)n * C + c] = 1.0f / (1.0f + __expf(-s));
+    }
+}
+
+hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, const float* fc2, float* scale,
+                     hipStream_t stream) {
+    if (C > 512 || (C & 63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_se, dim3(N), dim3(256), 0, stream, res, HW, C, fc1, fc2, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// out = res * se_scale + shortcut    (bottleneck_IR_SE.forward, model_ir_se50.py:73-76;
+// MaxPool2d(1, stride) shortcut = strided subsample, :60)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_combine(const float* __restrict__ res, const float* __restrict__ scale,
+                                                const float* __restrict__ sc, const float* __restrict__ x,
+                                                float* __restrict__ out, int HoWo, int Wo, int C, int stride,
+                                                long long total4) {
+    const int cq = C >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / cq;
+        const int c4 = (int)(idx - m * cq) * 4;
+        const int n = (int)(m / HoWo);
+        const f32x4 r = *reinterpret_cast<const f32x4*>(res + m * C + c4);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + (size_t)n * C + c4);
+        f32x4 sh;
+        if (sc) {
+            sh = *reinterpret_cast<const f32x4*>(sc + m * C + c4);
+        } else if (stride == 1) {
+            sh = *reinterpret_cast<const f32x4*>(x + m * C + c4);
+        } else {
+            const int rem = (int)(m - (long long)n * HoWo);
+            const int ho = rem / Wo, wo = rem - ho * Wo;
+            const long long pin = ((long long)n * (HoWo / Wo) * stride + (long long)ho * stride) * (Wo * stride) + wo * stride;
+            sh = *reinterpret_cast<const f32x4*>(x + pin * C + c4);
+        }
+        *reinterpret_cast<f32x4*>(out + m * C + c4) = r * s + sh;
+    }
+}
+
+hipError_t launch_combine(const float* res, const float* scale, const float* sc, const float* x, float* out,
+                          int N, int Ho, int Wo, int C, int stride, hipStream_t stream) {
+    const long long total4 = (long long)N * Ho * Wo * (C >> 2);
+    unsigned blocks = (unsigned)((total4 + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, stream, res, scale, sc, x, out, Ho * Wo, Wo, C, stride,
+                       total4);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_affine(const float* __restrict__ x, const float* __restrict__ s,
+                                               const float* __restrict__ t, float* __restrict__ y, int C,
+                                               long long total4) {
+    const int cq = C >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+        const int c4 = (int)(idx % cq) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx * 4);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s + c4);
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(t + c4);
+        *reinterpret_cast<f32x4*>(y + idx * 4) = v * sv + tv;
+    }
+}
+
+hipError_t launch_affine(const float* x, const float* s, const float* t, float* y, int M, int C, hipStream_t stream) {
+    const long long total4 = (long long)M * (C >> 2);
+    unsigned blocks = (unsigned)((total4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_affine, dim3(blocks), dim3(256), 0, stream, x, s, t, y, C, total4);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Head finish: f = l2_norm(sum of split-K slabs + bias)   (model_ir_se50.py:13-16,124-125,141)
+// one block (256 threads) per image, C == 512
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ partial, int splits, int N, int C,
+                                                    const float* __restrict__ bias, float* __restrict__ f) {
+    __shared__ float s_red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float v[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int c = tid + e * 256;
+        float s = bias[c];
+        for (int k = 0; k < splits; ++k) s += partial[((size_t)k * N + n) * C + c];
+        v[e] = s;
+        ss += s * s;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) f[(size_t)n * C + tid + e * 256] = v[e] / nrm;
+}
+
+hipError_t launch_head_finish(const float* partial, int splits, int N, int C, const float* bias, float* f,
+                              hipStream_t stream) {
+    if (C != 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_head_finish, dim3(N), dim3(256), 0, stream, partial, splits, N, C, bias, f);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// [N,P,C] (pitch) <-> [N,C,P] through a 64-channel LDS tile; P <= 64
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nhwc_to_nchw(const float* __restrict__ in, int in_pitch,
+                                                     float* __restrict__ out, int P, int C) {
+    __shared__ float tile[64 * 65];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int e = tid; e < P * 64; e += 256) {
+        const int p = e >> 6, c = e & 63;
+        tile[p * 65 + c] = in[((size_t)n * P + p) * in_pitch + c0 + c];
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * P; e += 256) {
+        const int c = e / P, p = e - c * P;
+        out[((size_t)n * C + c0 + c) * P + p] = tile[p * 65 + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out,
+                                                     int out_pitch, int P, int C) {
+    __shared__ float tile[64 * 65];
+    const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int e = tid; e < 64 * P; e += 256) {
+        const int c = e / P, p = e - c * P;
+        tile[p * 65 + c] = in[((size_t)n * C + c0 + c) * P + p];
+    }
+    __syncthreads();
+    for (int e = tid; e < P * 64; e += 256) {
+        const int p = e >> 6, c = e & 63;
+        out[((size_t)n * P + p) * out_pitch + c0 + c] = tile[p * 65 + c];
+    }
+}
+
+hipError_t launch_nhwc_to_nchw(const float* in, int in_pitch, float* out, int N, int P, int C, hipStream_t stream) {
+    if (P > 64 || (C & 63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3(C / 64, N), dim3(256), 0, stream, in, in_pitch, out, P, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int out_pitch, int N, int P, int C, hipStream_t stream) {
+    if (P > 64 || (C & 63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3(C / 64, N), dim3(256), 0, stream, in, out, out_pitch, P, C);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy_slice(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                   int pitch, int coff, long long total4) {
+    const int cq = C >> 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / cq;
+        const int c4 = (int)(idx - m * cq) * 4;
+        *reinterpret_cast<f32x4*>(out + m * pitch + coff + c4) = *reinterpret_cast<const f32x4*>(in + idx * 4);
+    }
+}
+
+hipError_t launch_copy_slice(const float* in, float* out, int M, int C, int pitch, int coff, hipStream_t stream) {
+    const long long total4 = (long long)M * (C >> 2);
+    unsigned blocks = (unsigned)((total4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_copy_slice, dim3(blocks), dim3(256), 0, stream, in, out, C, pitch, coff, total4);
+    return hipGetLastError();
+}
+
+// cosine score of lfw/lfw_eval.py:246,248: one wave per pair
+__global__ __launch_bounds__(256) void k_cosine(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                               int dim, float* __restrict__ score) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float ab = 0.f, aa = 0.f, bb = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        const float x = a[(size_t)row * dim + c], y = b[(size_t)row * dim + c];
+        ab += x * y;
+        aa += x * x;
+        bb += y * y;
+    }
+    ab = wave_sum(ab);
+    aa = wave_sum(aa);
+    bb = wave_sum(bb);
+    if (lane == 0) score[row] = ab / (sqrtf(aa) * sqrtf(bb) + 1e-8f);
+}
+
+hipError_t launch_cosine(const float* a, const float* b, int n, int dim, float* score, hipStream_t stream) {
+    hipLaunchKernelGGL(k_cosine, dim3((n + 3) / 4), dim3(256), 0, stream, a, b, n, dim, score);
+    return hipGetLastError();
+}
+
+}  // namespace ffr

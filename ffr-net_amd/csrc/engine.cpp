@@ -1,0 +1,915 @@
+// libffrnet_hip.so: C ABI (include/ffrnet.h), weight packer and forward pipelines of the
+// MI355X-native FFR-Net embedding path.  Host code only; the kernels live in *.hip.
+//
+// Reference behaviour restated here (paths relative to the reference repository):
+//   Backbone.forward            pretrain/model_ir_se50.py:136-141
+//   bottleneck_IR_SE / SEModule pretrain/model_ir_se50.py:18-36,56-76
+//   RecNet.forward (label=None) models/recnet.py:398-426
+//   calculate_distance cosine   lfw/lfw_eval.py:246,248
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ffrnet.h"
+#include "ffr_kernels.h"
+
+using namespace ffr;
+
+namespace {
+
+const double BN_EPS = 1e-5;
+std::string g_err = "";
+
+struct ConvW {
+    int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, R = 1, S = 1, stride = 1, pad = 0, pad_mode = 0, border = 0;
+    float* w = nullptr;
+    float* bias = nullptr;
+    float* slope = nullptr;
+};
+
+struct Block {
+    int cin = 0, depth = 0, stride = 1;
+    bool has_sc = false;
+    ConvW c1, c2, sc;
+    float* fc1 = nullptr;
+    float* fc2 = nullptr;
+};
+
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int kc;
+    double flops, bytes;
+};
+
+}  // namespace
+
+struct ffr_handle {
+    int device = 0;
+    std::string err;
+    float* zero = nullptr;   // 256 B zero page
+    // weights
+    std::vector<void*> enc_allocs, rec_allocs;
+    bool enc_loaded = false, rec_loaded = false;
+    float *stem_w = nullptr, *stem_b = nullptr, *stem_s = nullptr;
+    Block blocks[24];
+    float *bn_s = nullptr, *bn_t = nullptr;
+    ConvW fc;
+    ConvW sp[9], fm[3], mg[3];
+    ChannelPathWeights cw{};
+    // workspace arena
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> prof_log;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(ffr_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIPCK(h, expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(h, FFR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define RC(expr)                  \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != FFR_OK) return _rc; \
+    } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- profiling scope: hipEvents on the launch stream around one launch -----------------
+struct Scope {
+    ffr_handle* h;
+    hipStream_t st;
+    ProfRec r;
+    bool on;
+    Scope(ffr_handle* h_, hipStream_t st_, int kc, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); }
+            else hipEventCreate(&e);
+            return e;
+        };
+        r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes;
+        hipEventRecord(r.e0, st);
+    }
+    ~Scope() {
+        if (!on) return;
+        hipEventRecord(r.e1, st);
+        h->prof_log.push_back(r);
+    }
+};
+
+// ---- host-side state_dict access -----------------------------------------------------------
+struct SD {
+    std::map<std::string, const ffr_tensor_desc*> m;
+    ffr_handle* h;
+    int rc = FFR_OK;
+    const float* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = m.find(name);
+        if (it == m.end()) { rc = fail(h, FFR_ERR_KEY, "state_dict entry '%s' is missing", name.c_str()); return nullptr; }
+        const ffr_tensor_desc* d = it->second;
+        bool ok = d->data && d->ndim == (int)shape.size();
+        int i = 0;
+        for (int64_t s : shape) { if (ok && d->shape[i] != s) ok = false; ++i; }
+        if (!ok) { rc = fail(h, FFR_ERR_KEY, "state_dict entry '%s' has an unexpected shape", name.c_str()); return nullptr; }
+        return d->data;
+    }
+};
+
+struct BNFold { std::vector<double> s, t; };
+bool bn_fold(SD& sd, const std::string& p, int C, BNFold& o) {
+    const float* g = sd.get(p + ".weight", {C});
+    const float* b = sd.get(p + ".bias", {C});
+    const float* mu = sd.get(p + ".running_mean", {C});
+    const float* var = sd.get(p + ".running_var", {C});
+    if (!g || !b || !mu || !var) return false;
+    o.s.resize(C); o.t.resize(C);
+    for (int c = 0; c < C; ++c) {
+        o.s[c] = (double)g[c] / std::sqrt((double)var[c] + BN_EPS);
+        o.t[c] = (double)b[c] - (double)mu[c] * o.s[c];
+    }
+    return true;
+}
+
+int upload(ffr_handle* h, std::vector<void*>& owner, const std::vector<float>& v, float** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, v.size() * sizeof(float)) != hipSuccess)
+        return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu weight bytes failed", v.size() * sizeof(float));
+    owner.push_back(p);
+    HIPCK(h, hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return FFR_OK;
+}
+
+// Pack one convolution: W[cout][cin][R][S] -> [cout_pad][(r*S+s)*cin_pad + ci], with an
+// optional per-input-channel affine folded in front (pre-conv BatchNorm: scale into the
+// weights, shift into one bias per zero-padding border class) and an optional
+// per-output-channel affine behind it (post-conv BatchNorm).
+int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout, int cin, int R, int S,
+              const BNFold* in_bn, const BNFold* out_bn, const float* slope, int stride, int pad, int pad_mode,
+              ConvW* L) {
+    L->cin = cin; L->cout = cout; L->R = R; L->S = S; L->stride = stride; L->pad = pad; L->pad_mode = pad_mode;
+    L->cin_pad = round_up(cin, 32);
+    L->cout_pad = round_up(cout, 64);
+    L->border = in_bn ? 1 : 0;
+    const int KK = R * S * L->cin_pad;
+    std::vector<float> wp((size_t)L->cout_pad * KK, 0.f);
+    const int ncls = L->border ? 9 : 1;
+    std::vector<float> bias((size_t)ncls * L->cout_pad, 0.f);
+    std::vector<double> tap(R * S);
+    for (int co = 0; co < cout; ++co) {
+        const double g = out_bn ? out_bn->s[co] : 1.0;
+        const double b = out_bn ? out_bn->t[co] : 0.0;
+        for (int r = 0; r < R; ++r)
+            for (int s = 0; s < S; ++s) {
+                double tsum = 0.0;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const double wv = W[(((size_t)co * cin + ci) * R + r) * S + s];
+                    const double si = in_bn ? in_bn->s[ci] : 1.0;
+                    wp[(size_t)co * KK + (size_t)(r * S + s) * L->cin_pad + ci] = (float)(wv * si * g);
+                    if (in_bn) tsum += wv * in_bn->t[ci];
+                }
+                tap[r * S + s] = tsum;
+            }
+        if (L->border) {
+            // class (rc,cc): rc 0 = top row of taps out of bounds, 1 = none, 2 = bottom row; same for columns
+            for (int rc = 0; rc < 3; ++rc)
+                for (int cc = 0; cc < 3; ++cc) {
+                    double acc = 0.0;
+                    for (int r = 0; r < R; ++r) {
+                        if ((rc == 0 && r == 0) || (rc == 2 && r == R - 1)) continue;
+                        for (int s = 0; s < S; ++s) {
+                            if ((cc == 0 && s == 0) || (cc == 2 && s == S - 1)) continue;
+                            acc += tap[r * S + s];
+                        }
+                    }
+                    bias[(size_t)(rc * 3 + cc) * L->cout_pad + co] = (float)(g * acc + b);
+                }
+        } else {
+            bias[co] = (float)b;
+        }
+    }
+    RC(upload(h, owner, wp, &L->w));
+    RC(upload(h, owner, bias, &L->bias));
+    L->slope = nullptr;
+    if (slope) {
+        std::vector<float> sl(L->cout_pad, 0.f);
+        for (int co = 0; co < cout; ++co) sl[co] = slope[co];
+        RC(upload(h, owner, sl, &L->slope));
+    }
+    return FFR_OK;
+}
+
+void free_list(std::vector<void*>& v) {
+    for (void* p : v) hipFree(p);
+    v.clear();
+}
+
+const int STAGES[4][3] = {{64, 64, 3}, {64, 128, 4}, {128, 256, 14}, {256, 512, 3}};
+
+void block_table(int cin[24], int depth[24], int stride[24]) {
+    int k = 0;
+    for (auto& st : STAGES)
+        for (int u = 0; u < st[2]; ++u) {
+            cin[k] = u == 0 ? st[0] : st[1];
+            depth[k] = st[1];
+            stride[k] = u == 0 ? 2 : 1;
+            ++k;
+        }
+}
+
+// ---- convolution dispatch --------------------------------------------------------------
+void plan_conv(long long M, int cout_pad, int nkt, int force_tile, int force_split, int* tile, int* splits) {
+    static const double eff[IGEMM_NTILES + 1] = {0, 1.00, 1.04, 1.12, 1.02};
+    int best = 0;
+    double best_cost = 1e300;
+    for (int t = 1; t <= 3; ++t) {     // 256x64 stays opt-in (1 block/CU)
+        int bm, bn;
+        igemm_tile_shape(t, &bm, &bn);
+        if (cout_pad % bn) continue;
+        const double tiles = (double)((M + bm - 1) / bm) * (cout_pad / bn);
+        const double rounds = std::ceil(tiles / 256.0);
+        const double cost = rounds * bm * bn * eff[t];
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    if (force_tile >= 1 && force_tile <= IGEMM_NTILES) best = force_tile;
+    int bm, bn;
+    igemm_tile_shape(best, &bm, &bn);
+    const long long tiles = ((M + bm - 1) / bm) * (cout_pad / bn);
+    int sp = 1;
+    if (force_split > 0) sp = force_split;
+    else if (tiles < 128 && nkt >= 16) {
+        sp = (int)(256 / tiles);
+        if (sp > nkt / 8) sp = nkt / 8;
+        if (sp > 32) sp = 32;
+        if (sp < 1) sp = 1;
+    }
+    if (sp > nkt) sp = nkt;
+    *tile = best;
+    *splits = sp;
+}
+
+struct ConvCall {
+    const float* x; int N, H, W, in_pitch;
+    const float* resid; int res_pitch;
+    float* out; int out_pitch, out_coff, cout_store;
+    int flags; int tile; int splitk;
+    float* partial; size_t partial_cap;   // floats
+    bool partial_only;                    // FC: leave the slabs for a custom finish
+    int* splits_out;
+};
+
+int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
+    IgemmArgs a{};
+    a.x = c.x; a.w = L.w; a.bias = L.bias; a.slope = L.slope; a.resid = c.resid; a.out = c.out; a.zero = h->zero;
+    a.N = c.N; a.H = c.H; a.W = c.W;
+    a.Ho = (c.H + 2 * L.pad - L.R) / L.stride + 1;
+    a.Wo = (c.W + 2 * L.pad - L.S) / L.stride + 1;
+    a.in_pitch = c.in_pitch; a.cin_pad = L.cin_pad; a.R = L.R; a.S = L.S; a.stride = L.stride; a.pad = L.pad;
+    a.pad_mode = L.pad_mode;
+    const long long M = (long long)c.N * a.Ho * a.Wo;
+    if (M <= 0 || M > 0x7fffffffLL) return fail(h, FFR_ERR_ARG, "conv: bad M");
+    a.M = (int)M; a.KK = L.R * L.S * L.cin_pad; a.nkt = a.KK / 32;
+    a.cout_pad = L.cout_pad; a.cout_store = c.cout_store; a.out_pitch = c.out_pitch; a.out_coff = c.out_coff;
+    a.res_pitch = c.res_pitch; a.border_bias = L.border; a.flags = c.flags;
+    if (L.pad_mode == 1 && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "reflect pad needs H,W >= 2");
+    if (L.border && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "border-class bias needs H,W >= 2");
+    int tile, splits;
+    plan_conv(M, L.cout_pad, a.nkt, c.tile, c.splitk, &tile, &splits);
+    if (splits > 1 || c.partial_only) {
+        if (L.border) splits = c.partial_only ? splits : 1;
+        while (splits > 1 && (size_t)splits * M * L.cout_pad > c.partial_cap) --splits;
+        if (c.partial_only && (size_t)splits * M * L.cout_pad > c.partial_cap)
+            return fail(h, FFR_ERR_NOMEM, "split-K workspace too small");
+    }
+    int bm, bn;
+    igemm_tile_shape(tile, &bm, &bn);
+    a.mtiles = (int)((M + bm - 1) / bm);
+    a.ntiles = L.cout_pad / bn;
+    a.kt_per_split = (a.nkt + splits - 1) / splits;
+    splits = (a.nkt + a.kt_per_split - 1) / a.kt_per_split;
+    a.splits = splits;
+    a.partial = (splits > 1 || c.partial_only) ? c.partial : nullptr;
+    if (c.splits_out) *c.splits_out = splits;
+    const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
+    const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
+    {
+        Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes);
+        HIPCK(h, launch_igemm(a, tile, st));
+    }
+    if (a.partial && !c.partial_only) {
+        Scope s(h, st, FFR_KC_CONV_IGEMM, 0, 0);
+        HIPCK(h, launch_splitk_reduce(a, st));
+    }
+    return FFR_OK;
+}
+
+// ---- workspace ---------------------------------------------------------------------------
+struct Arena {
+    char* base; size_t off = 0, cap;
+    Arena(char* b, size_t c) : base(b), cap(c) {}
+    float* take(size_t floats) {
+        size_t bytes = (floats * 4 + 255) & ~(size_t)255;
+        float* p = base ? (float*)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+struct Work {
+    // encoder
+    float *bufA, *bufB, *t1, *res, *sc, *scale, *trunk_bn;
+    // shared
+    float* partial; size_t partial_cap;
+    // recnet
+    float *X, *bufS, *bufF, *bufM, *s256a, *s256b, *s256c, *ms, *m512a, *m512b, *m512c, *dbg;
+    size_t total;
+};
+
+Work layout(char* base, int N, int H, int W) {
+    Arena a(base, 0);
+    Work w{};
+    const size_t S0 = (size_t)N * H * W * 64;
+    const size_t hw16 = (size_t)(H / 16) * (W / 16);
+    w.bufA = a.take(S0);
+    w.bufB = a.take(S0 / 4);
+    w.t1 = a.take(S0);
+    w.res = a.take(S0 / 4);
+    w.sc = a.take(S0 / 8);
+    w.scale = a.take((size_t)N * 512);
+    w.trunk_bn = a.take((size_t)N * hw16 * 512);
+    w.partial_cap = (size_t)32 * (N > 64 ? N : 64) * 512 + (size_t)8 * 1024 * 1024;
+    w.partial = a.take(w.partial_cap);
+    const size_t P = (size_t)N * 49;
+    w.X = a.take(P * 512);
+    w.bufS = a.take(P * 576);
+    w.bufF = a.take(P * 1024);
+    w.bufM = a.take(P * 1536);
+    w.s256a = a.take(P * 256);
+    w.s256b = a.take(P * 256);
+    w.s256c = a.take(P * 256);
+    w.ms = a.take(P * 64);
+    w.m512a = a.take(P * 512);
+    w.m512b = a.take(P * 512);
+    w.m512c = a.take(P * 512);
+    w.dbg = a.take(P * 512);
+    w.total = a.off;
+    return w;
+}
+
+int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
+    const size_t need = layout(nullptr, N, H, W).total;
+    if (need > h->arena_bytes) {
+        if (h->arena) { hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; }
+        void* p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess)
+            return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu workspace bytes failed", need);
+        h->arena = (char*)p;
+        h->arena_bytes = need;
+    }
+    *w = layout(h->arena, N, H, W);
+    return FFR_OK;
+}
+
+// ---- encoder ---------------------------------------------------------------------------
+// Runs stem + n_blocks bottlenecks; *out_ptr = NHWC result, *oh/*ow/*oc its geometry.
+int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, int W, int n_blocks, hipStream_t st,
+              float** out_ptr, int* oh, int* ow, int* oc) {
+    {
+        Scope s(h, st, FFR_KC_STEM, 2.0 * N * H * W * 64 * 27, 4.0 * N * H * W * (3 + 64));
+        HIPCK(h, launch_stem(x_nchw, h->stem_w, h->stem_b, h->stem_s, w.bufA, N, H, W, st));
+    }
+    float* cur = w.bufA;
+    float* nxt = w.bufB;
+    int ch = H, cw = W, cc = 64;
+    for (int i = 0; i < n_blocks; ++i) {
+        const Block& b = h->blocks[i];
+        const int ho = ch / b.stride, wo = cw / b.stride;
+        ConvCall c1{};
+        c1.x = cur; c1.N = N; c1.H = ch; c1.W = cw; c1.in_pitch = b.cin;
+        c1.out = w.t1; c1.out_pitch = b.depth; c1.cout_store = b.depth;
+        c1.partial = w.partial; c1.partial_cap = w.partial_cap;
+        RC(run_conv(h, b.c1, c1, st));
+        ConvCall c2{};
+        c2.x = w.t1; c2.N = N; c2.H = ch; c2.W = cw; c2.in_pitch = b.depth;
+        c2.out = w.res; c2.out_pitch = b.depth; c2.cout_store = b.depth;
+        c2.partial = w.partial; c2.partial_cap = w.partial_cap;
+        RC(run_conv(h, b.c2, c2, st));
+        {
+            const double e = (double)N * ho * wo * b.depth;
+            Scope s(h, st, FFR_KC_SE, e + 4.0 * N * b.depth * (b.depth / 16), 4.0 * e);
+            HIPCK(h, launch_se(w.res, N, ho * wo, b.depth, b.fc1, b.fc2, w.scale, st));
+        }
+        const float* scp = nullptr;
+        if (b.has_sc) {
+            ConvCall cs{};
+            cs.x = cur; cs.N = N; cs.H = ch; cs.W = cw; cs.in_pitch = b.cin;
+            cs.out = w.sc; cs.out_pitch = b.depth; cs.cout_store = b.depth;
+            cs.partial = w.partial; cs.partial_cap = w.partial_cap;
+            RC(run_conv(h, b.sc, cs, st));
+            scp = w.sc;
+        }
+        {
+            const double e = (double)N * ho * wo * b.depth;
+            Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 12.0 * e);
+            HIPCK(h, launch_combine(w.res, w.scale, scp, cur, nxt, N, ho, wo, b.depth, b.stride, st));
+        }
+        float* t = cur; cur = nxt; nxt = t;
+        ch = ho; cw = wo; cc = b.depth;
+    }
+    *out_ptr = cur; *oh = ch; *ow = cw; *oc = cc;
+    return FFR_OK;
+}
+
+// trunk -> featmap (NHWC in w.X / w.trunk_bn) and f
+int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
+                hipStream_t st) {
+    float* t; int oh, ow, oc;
+    RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc));
+    const int P = oh * ow;
+    if (featmap_nhwc) {
+        Scope s(h, st, FFR_KC_HEAD, 2.0 * N * P * 512, 8.0 * N * P * 512);
+        HIPCK(h, launch_affine(t, h->bn_s, h->bn_t, featmap_nhwc, N * P, 512, st));
+    }
+    if (f) {
+        if (P != 49) return fail(h, FFR_ERR_UNSUPPORTED, "output_layer needs a 7x7 trunk map (112x112 input)");
+        ConvCall c{};
+        c.x = t; c.N = N; c.H = 1; c.W = 1; c.in_pitch = 25088;
+        c.out = nullptr; c.out_pitch = 512; c.cout_store = 512;
+        c.partial = w.partial; c.partial_cap = w.partial_cap; c.partial_only = true;
+        int splits = 1;
+        c.splits_out = &splits;
+        RC(run_conv(h, h->fc, c, st));
+        Scope s(h, st, FFR_KC_HEAD, 3.0 * N * 512, 4.0 * N * 512 * (splits + 1));
+        HIPCK(h, launch_head_finish(w.partial, splits, N, 512, h->fc.bias, f, st));
+    }
+    return FFR_OK;
+}
+
+// ---- recnet ----------------------------------------------------------------------------
+struct RecDebug { float *ss_space, *M_space, *feat_space, *feat_channel_raw, *feat_channel; };
+
+int conv_rec(ffr_handle* h, const Work& w, const ConvW& L, const float* x, int in_pitch, const float* resid,
+             int res_pitch, float* out, int out_pitch, int out_coff, int flags, int N, hipStream_t st) {
+    ConvCall c{};
+    c.x = x; c.N = N; c.H = 7; c.W = 7; c.in_pitch = in_pitch; c.resid = resid; c.res_pitch = res_pitch;
+    c.out = out; c.out_pitch = out_pitch; c.out_coff = out_coff; c.cout_store = L.cout_pad; c.flags = flags;
+    c.partial = w.partial; c.partial_cap = w.partial_cap;
+    return run_conv(h, L, c, st);
+}
+
+// X (w.X, [N,49,512]) must be filled.  Produces feat_new NHWC in w.m512c and f_new.
+int run_recnet(ffr_handle* h, const Work& w, int N, float* f_new, const RecDebug* dbg, hipStream_t st) {
+    const int M = N * 49;
+    {
+        Scope s(h, st, FFR_KC_LAYOUT, 0, 16.0 * M * 512);
+        HIPCK(h, launch_copy_slice(w.X, w.bufS, M, 512, 576, 0, st));
+        HIPCK(h, launch_copy_slice(w.X, w.bufM, M, 512, 1536, 1024, st));
+    }
+    {
+        Scope s(h, st, FFR_KC_SELFSIM, 2.0 * N * 49 * 49 * 512, 4.0 * N * (49 * 512 + 49 * 49));
+        HIPCK(h, launch_selfsim_space(w.X, w.bufS, 576, dbg ? dbg->ss_space : nullptr, N, st));
+    }
+    {
+        // ss_channel Gram + Conv4Channel (6 linears) + M_channel @ X, algorithmic (unfused) count
+        const double fl = 2.0 * N * (512.0 * 512 * 49 + 512.0 * (561 * 32 + 5 * 32 * 512) + 512.0 * 512 * 49);
+        Scope s(h, st, FFR_KC_CHANNEL, fl, 4.0 * N * (49 * 512 * 3));
+        HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st));
+    }
+    // Conv4Space (recnet.py:362-371)
+    RC(conv_rec(h, w, h->sp[0], w.bufS, 576, nullptr, 0, w.s256a, 256, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[1], w.s256a, 256, nullptr, 0, w.s256b, 256, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[2], w.s256b, 256, w.s256a, 256, w.s256c, 256, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[3], w.s256c, 256, nullptr, 0, w.s256a, 128, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[4], w.s256a, 128, nullptr, 0, w.s256b, 128, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[5], w.s256b, 128, w.s256a, 128, w.s256c, 128, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[6], w.s256c, 128, nullptr, 0, w.s256a, 64, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[7], w.s256a, 64, nullptr, 0, w.s256b, 64, 0, 0, N, st));
+    RC(conv_rec(h, w, h->sp[8], w.s256b, 64, w.s256a, 64, w.ms, 64, 0, 1 /*sigmoid*/, N, st));
+    {
+        Scope s(h, st, FFR_KC_SPACE, 2.0 * N * 512 * 49 * 49, 4.0 * N * (2 * 49 * 512 + 49 * 49));
+        HIPCK(h, launch_space_apply(w.X, w.ms, 64, w.bufM, 1536, 0, N, st));
+    }
+    // ChannelFlipMerge (recnet.py:387-390,416-418) -> bufM channels [512,1024)
+    RC(conv_rec(h, w, h->fm[0], w.bufF, 1024, nullptr, 0, w.m512a, 512, 0, 0, N, st));
+    RC(conv_rec(h, w, h->fm[1], w.m512a, 512, nullptr, 0, w.m512b, 512, 0, 0, N, st));
+    RC(conv_rec(h, w, h->fm[2], w.m512b, 512, w.m512a, 512, w.bufM, 1536, 512, 0, N, st));
+    // Conv4Merge (recnet.py:391-394,420-421)
+    RC(conv_rec(h, w, h->mg[0], w.bufM, 1536, nullptr, 0, w.m512a, 512, 0, 0, N, st));
+    RC(conv_rec(h, w, h->mg[1], w.m512a, 512, nullptr, 0, w.m512b, 512, 0, 0, N, st));
+    RC(conv_rec(h, w, h->mg[2], w.m512b, 512, w.m512a, 512, w.m512c, 512, 0, 0, N, st));
+    if (f_new) {
+        Scope s(h, st, FFR_KC_HEAD, (double)N * 49 * 512, 4.0 * N * 50 * 512);
+        HIPCK(h, launch_avgpool49(w.m512c, f_new, N, 512, st));
+    }
+    if (dbg) {
+        Scope s(h, st, FFR_KC_LAYOUT, 0, 0);
+        if (dbg->M_space) {   // M_space[n][i][j] = ms[n][j][i]: "NCHW" with C = 49 of a pitch-64 buffer
+            // transpose kernel works on 64-channel groups: use dbg scratch [N,64,49] then compact on host side
+            HIPCK(h, launch_nhwc_to_nchw(w.ms, 64, w.dbg, N, 49, 64, st));
+            for (int n = 0; n < N; ++n)
+                HIPCK(h, hipMemcpyAsync(dbg->M_space + (size_t)n * 2401, w.dbg + (size_t)n * 64 * 49,
+                                        2401 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        if (dbg->feat_space) HIPCK(h, launch_nhwc_to_nchw(w.bufM, 1536, dbg->feat_space, N, 49, 512, st));
+        if (dbg->feat_channel_raw) HIPCK(h, launch_nhwc_to_nchw(w.bufF + 512, 1024, dbg->feat_channel_raw, N, 49, 512, st));
+        if (dbg->feat_channel) HIPCK(h, launch_nhwc_to_nchw(w.bufM + 512, 1536, dbg->feat_channel, N, 49, 512, st));
+    }
+    return FFR_OK;
+}
+
+int check_fwd(ffr_handle* h, bool need_enc, bool need_rec, int N) {
+    if (!h) return fail(nullptr, FFR_ERR_ARG, "null handle");
+    if (N <= 0) return fail(h, FFR_ERR_ARG, "N must be positive");
+    if (need_enc && !h->enc_loaded) return fail(h, FFR_ERR_STATE, "encoder weights are not loaded");
+    if (need_rec && !h->rec_loaded) return fail(h, FFR_ERR_STATE, "recnet weights are not loaded");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    return FFR_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char* ffr_version(void) { return "ffrnet-hip 0.1 (gfx950)"; }
+
+const char* ffr_last_error(const ffr_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int ffr_create(ffr_handle** out, int device) {
+    if (!out) return fail(nullptr, FFR_ERR_ARG, "ffr_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, FFR_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(nullptr, FFR_ERR_ARG, "device %d out of range (%d devices)", device, count);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FFR_ERR_HIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, FFR_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FFR_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    ffr_handle* h = new ffr_handle();
+    h->device = device;
+    void* z = nullptr;
+    if (hipMalloc(&z, 256) != hipSuccess) { delete h; return fail(nullptr, FFR_ERR_NOMEM, "hipMalloc failed"); }
+    hipMemset(z, 0, 256);
+    h->zero = (float*)z;
+    hipError_t e = igemm_init();
+    if (e != hipSuccess) {
+        hipFree(z); delete h;
+        return fail(nullptr, FFR_ERR_HIP, "igemm_init: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return FFR_OK;
+}
+
+void ffr_destroy(ffr_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    free_list(h->enc_allocs);
+    free_list(h->rec_allocs);
+    if (h->arena) hipFree(h->arena);
+    if (h->zero) hipFree(h->zero);
+    for (auto& r : h->prof_log) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto e : h->ev_pool) hipEventDestroy(e);
+    delete h;
+}
+
+int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
+    if (!h || !t || n <= 0) return fail(h, FFR_ERR_ARG, "ffr_load_encoder: bad arguments");
+    RC(check_fwd(h, false, false, 1));
+    hipDeviceSynchronize();
+    free_list(h->enc_allocs);
+    h->enc_loaded = false;
+    SD sd; sd.h = h;
+    for (int i = 0; i < n; ++i) if (t[i].name) sd.m[t[i].name] = &t[i];
+    auto& own = h->enc_allocs;
+
+    // stem (model_ir_se50.py:118-120): BN folded into the weights, [27][64] tap-major
+    {
+        const float* W = sd.get("input_layer.0.weight", {64, 3, 3, 3});
+        BNFold bn;
+        if (!W || !bn_fold(sd, "input_layer.1", 64, bn)) return sd.rc;
+        const float* sl = sd.get("input_layer.2.weight", {64});
+        if (!sl) return sd.rc;
+        std::vector<float> w(27 * 64), b(64), s(64);
+        for (int co = 0; co < 64; ++co) {
+            for (int k = 0; k < 27; ++k) w[k * 64 + co] = (float)((double)W[co * 27 + k] * bn.s[co]);
+            b[co] = (float)bn.t[co];
+            s[co] = sl[co];
+        }
+        RC(upload(h, own, w, &h->stem_w));
+        RC(upload(h, own, b, &h->stem_b));
+        RC(upload(h, own, s, &h->stem_s));
+    }
+    int cin[24], depth[24], stride[24];
+    block_table(cin, depth, stride);
+    for (int i = 0; i < 24; ++i) {
+        Block& b = h->blocks[i];
+        b = Block();
+        b.cin = cin[i]; b.depth = depth[i]; b.stride = stride[i];
+        const std::string p = "body." + std::to_string(i);
+        BNFold bn1, bn2;
+        if (!bn_fold(sd, p + ".res_layer.0", b.cin, bn1) || !bn_fold(sd, p + ".res_layer.4", b.depth, bn2)) return sd.rc;
+        const float* W1 = sd.get(p + ".res_layer.1.weight", {b.depth, b.cin, 3, 3});
+        const float* sl = sd.get(p + ".res_layer.2.weight", {b.depth});
+        const float* W2 = sd.get(p + ".res_layer.3.weight", {b.depth, b.depth, 3, 3});
+        const float* f1 = sd.get(p + ".res_layer.5.fc1.weight", {b.depth / 16, b.depth, 1, 1});
+        const float* f2 = sd.get(p + ".res_layer.5.fc2.weight", {b.depth, b.depth / 16, 1, 1});
+        if (!W1 || !sl || !W2 || !f1 || !f2) return sd.rc;
+        RC(pack_conv(h, own, W1, b.depth, b.cin, 3, 3, &bn1, nullptr, sl, 1, 1, 0, &b.c1));
+        RC(pack_conv(h, own, W2, b.depth, b.depth, 3, 3, nullptr, &bn2, nullptr, b.stride, 1, 0, &b.c2));
+        RC(upload(h, own, std::vector<float>(f1, f1 + (size_t)b.depth / 16 * b.depth), &b.fc1));
+        RC(upload(h, own, std::vector<float>(f2, f2 + (size_t)b.depth / 16 * b.depth), &b.fc2));
+        b.has_sc = b.cin != b.depth;
+        if (b.has_sc) {
+            BNFold bns;
+            const float* Ws = sd.get(p + ".shortcut_layer.0.weight", {b.depth, b.cin, 1, 1});
+            if (!Ws || !bn_fold(sd, p + ".shortcut_layer.1", b.depth, bns)) return sd.rc;
+            RC(pack_conv(h, own, Ws, b.depth, b.cin, 1, 1, nullptr, &bns, nullptr, b.stride, 0, 0, &b.sc));
+        }
+    }
+    {   // Backbone.bn (:126,139)
+        BNFold bn;
+        if (!bn_fold(sd, "bn", 512, bn)) return sd.rc;
+        std::vector<float> s(512), tt(512);
+        for (int c = 0; c < 512; ++c) { s[c] = (float)bn.s[c]; tt[c] = (float)bn.t[c]; }
+        RC(upload(h, own, s, &h->bn_s));
+        RC(upload(h, own, tt, &h->bn_t));
+    }
+    {   // output_layer (:121-125): BN2d -> Flatten(NCHW) -> Linear -> BN1d as ONE GEMM on the NHWC trunk
+        BNFold b0, b4;
+        if (!bn_fold(sd, "output_layer.0", 512, b0) || !bn_fold(sd, "output_layer.4", 512, b4)) return sd.rc;
+        const float* W = sd.get("output_layer.3.weight", {512, 25088});
+        const float* bias = sd.get("output_layer.3.bias", {512});
+        if (!W || !bias) return sd.rc;
+        ConvW& L = h->fc;
+        L = ConvW();
+        L.cin = L.cin_pad = 25088; L.cout = L.cout_pad = 512; L.R = L.S = 1; L.stride = 1; L.pad = 0;
+        std::vector<float> wp((size_t)512 * 25088), bb(512);
+        for (int o = 0; o < 512; ++o) {
+            double acc = bias[o];
+            for (int c = 0; c < 512; ++c)
+                for (int p = 0; p < 49; ++p) {
+                    const double wv = W[(size_t)o * 25088 + c * 49 + p];
+                    wp[(size_t)o * 25088 + p * 512 + c] = (float)(wv * b0.s[c] * b4.s[o]);
+                    acc += wv * b0.t[c];
+                }
+            bb[o] = (float)(b4.s[o] * acc + b4.t[o]);
+        }
+        RC(upload(h, own, wp, &L.w));
+        RC(upload(h, own, bb, &L.bias));
+    }
+    h->enc_loaded = true;
+    return FFR_OK;
+}
+
+int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n) {
+    if (!h || !t || n <= 0) return fail(h, FFR_ERR_ARG, "ffr_load_recnet: bad arguments");
+    RC(check_fwd(h, false, false, 1));
+    hipDeviceSynchronize();
+    free_list(h->rec_allocs);
+    h->rec_loaded = false;
+    SD sd; sd.h = h;
+    for (int i = 0; i < n; ++i) if (t[i].name) sd.m[t[i].name] = &t[i];
+    auto& own = h->rec_allocs;
+
+    // ConvLayer = reflect-pad -> conv3x3 (no bias) -> BN -> PReLU   (recnet.py:52-85)
+    auto conv_layer = [&](const std::string& p, int cin, int cout, ConvW* L) -> int {
+        const float* W = sd.get(p + ".conv2d.weight", {cout, cin, 3, 3});
+        const float* sl = sd.get(p + ".relu.func.weight", {cout});
+        BNFold bn;
+        if (!W || !sl || !bn_fold(sd, p + ".norm.norm", cout, bn)) return sd.rc;
+        return pack_conv(h, own, W, cout, cin, 3, 3, nullptr, &bn, sl, 1, 1, 1, L);
+    };
+    RC(conv_layer("Conv4Space.0", 561, 256, &h->sp[0]));
+    RC(conv_layer("Conv4Space.1.conv1", 256, 256, &h->sp[1]));
+    RC(conv_layer("Conv4Space.1.conv2", 256, 256, &h->sp[2]));
+    RC(conv_layer("Conv4Space.2", 256, 128, &h->sp[3]));
+    RC(conv_layer("Conv4Space.3.conv1", 128, 128, &h->sp[4]));
+    RC(conv_layer("Conv4Space.3.conv2", 128, 128, &h->sp[5]));
+    RC(conv_layer("Conv4Space.4", 128, 49, &h->sp[6]));
+    RC(conv_layer("Conv4Space.5.conv1", 49, 49, &h->sp[7]));
+    RC(conv_layer("Conv4Space.5.conv2", 49, 49, &h->sp[8]));
+    RC(conv_layer("ChannelFlipMerge.0", 1024, 512, &h->fm[0]));
+    RC(conv_layer("ChannelFlipMerge.1.conv1", 512, 512, &h->fm[1]));
+    RC(conv_layer("ChannelFlipMerge.1.conv2", 512, 512, &h->fm[2]));
+    RC(conv_layer("Conv4Merge.0", 1536, 512, &h->mg[0]));
+    RC(conv_layer("Conv4Merge.1.conv1", 512, 512, &h->mg[1]));
+    RC(conv_layer("Conv4Merge.1.conv2", 512, 512, &h->mg[2]));
+
+    // Conv4Channel (recnet.py:372-386)
+    const float* W1 = sd.get("Conv4Channel.0.weight", {32, 561});
+    const float* b1 = sd.get("Conv4Channel.0.bias", {32});
+    const float* a1 = sd.get("Conv4Channel.1.func.weight", {512});
+    const float* W2 = sd.get("Conv4Channel.2.weight", {512, 32});
+    const float* b2 = sd.get("Conv4Channel.2.bias", {512});
+    const float* W3 = sd.get("Conv4Channel.3.weight", {32, 512});
+    const float* b3 = sd.get("Conv4Channel.3.bias", {32});
+    const float* a4 = sd.get("Conv4Channel.4.func.weight", {512});
+    const float* W5 = sd.get("Conv4Channel.5.weight", {512, 32});
+    const float* b5 = sd.get("Conv4Channel.5.bias", {512});
+    const float* W6 = sd.get("Conv4Channel.6.weight", {32, 512});
+    const float* b6 = sd.get("Conv4Channel.6.bias", {32});
+    const float* a7 = sd.get("Conv4Channel.7.func.weight", {512});
+    const float* W8 = sd.get("Conv4Channel.8.weight", {512, 32});
+    const float* b8 = sd.get("Conv4Channel.8.bias", {512});
+    if (!W1 || !b1 || !a1 || !W2 || !b2 || !W3 || !b3 || !a4 || !W5 || !b5 || !W6 || !b6 || !a7 || !W8 || !b8) return sd.rc;
+    std::vector<float> w1a(32 * 49), w1bT(512 * 32);
+    for (int j = 0; j < 32; ++j) {
+        for (int p = 0; p < 49; ++p) w1a[j * 49 + p] = W1[j * 561 + p];
+        for (int c = 0; c < 512; ++c) w1bT[c * 32 + j] = W1[j * 561 + 49 + c];
+    }
+    auto fold = [](const float* Wb /*[32][512]*/, const float* bb, const float* Wa /*[512][32]*/, const float* ba,
+                   std::vector<float>& A, std::vector<float>& d) {
+        A.assign(32 * 32, 0.f); d.assign(32, 0.f);
+        for (int j = 0; j < 32; ++j) {
+            double dd = bb[j];
+            for (int k = 0; k < 512; ++k) dd += (double)Wb[j * 512 + k] * ba[k];
+            d[j] = (float)dd;
+            for (int i = 0; i < 32; ++i) {
+                double s = 0;
+                for (int k = 0; k < 512; ++k) s += (double)Wb[j * 512 + k] * Wa[k * 32 + i];
+                A[j * 32 + i] = (float)s;
+            }
+        }
+    };
+    std::vector<float> A2, d2, A3, d3;
+    fold(W3, b3, W2, b2, A2, d2);
+    fold(W6, b6, W5, b5, A3, d3);
+    float* p;
+    ChannelPathWeights& cw = h->cw;
+    RC(upload(h, own, w1a, &p)); cw.w1a = p;
+    RC(upload(h, own, w1bT, &p)); cw.w1b = p;
+    RC(upload(h, own, std::vector<float>(b1, b1 + 32), &p)); cw.b1 = p;
+    RC(upload(h, own, std::vector<float>(a1, a1 + 512), &p)); cw.a1 = p;
+    RC(upload(h, own, A2, &p)); cw.A2 = p;
+    RC(upload(h, own, d2, &p)); cw.d2 = p;
+    RC(upload(h, own, std::vector<float>(a4, a4 + 512), &p)); cw.a4 = p;
+    RC(upload(h, own, A3, &p)); cw.A3 = p;
+    RC(upload(h, own, d3, &p)); cw.d3 = p;
+    RC(upload(h, own, std::vector<float>(a7, a7 + 512), &p)); cw.a7 = p;
+    RC(upload(h, own, std::vector<float>(W8, W8 + 512 * 32), &p)); cw.w8 = p;
+    RC(upload(h, own, std::vector<float>(b8, b8 + 512), &p)); cw.b8 = p;
+    h->rec_loaded = true;
+    return FFR_OK;
+}
+
+size_t ffr_workspace_bytes(const ffr_handle* h, int N, int H, int W) {
+    (void)h;
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return layout(nullptr, N, H, W).total;
+}
+
+int ffr_reserve(ffr_handle* h, int N, int H, int W) {
+    RC(check_fwd(h, false, false, N));
+    Work w;
+    return ensure_arena(h, N, H, W, &w);
+}
+
+int ffr_encoder_forward(ffr_handle* h, const float* x, int N, int H, int W, float* featmap_nchw, float* f, void* stream) {
+    RC(check_fwd(h, true, false, N));
+    if (!x) return fail(h, FFR_ERR_ARG, "x is null");
+    if (H < 32 || W < 32 || (H & 15) || (W & 15)) return fail(h, FFR_ERR_ARG, "H and W must be multiples of 16, >= 32");
+    if (f && (H != 112 || W != 112)) return fail(h, FFR_ERR_UNSUPPORTED, "f needs a 112x112 input (Linear(512*7*7,512))");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N, H, W, &w));
+    RC(run_encoder(h, w, x, N, H, W, featmap_nchw ? w.trunk_bn : nullptr, f, st));
+    if (featmap_nchw) {
+        Scope s(h, st, FFR_KC_LAYOUT, 0, 8.0 * N * (H / 16) * (W / 16) * 512);
+        HIPCK(h, launch_nhwc_to_nchw(w.trunk_bn, 512, featmap_nchw, N, (H / 16) * (W / 16), 512, st));
+    }
+    return FFR_OK;
+}
+
+int ffr_recnet_forward(ffr_handle* h, const float* featmap_nchw, int N, float* f_new, float* feat_new_nchw, void* stream) {
+    RC(check_fwd(h, false, true, N));
+    if (!featmap_nchw) return fail(h, FFR_ERR_ARG, "featmap is null");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N, 112, 112, &w));
+    {
+        Scope s(h, st, FFR_KC_LAYOUT, 0, 8.0 * N * 49 * 512);
+        HIPCK(h, launch_nchw_to_nhwc(featmap_nchw, w.X, 512, N, 49, 512, st));
+    }
+    RC(run_recnet(h, w, N, f_new, nullptr, st));
+    if (feat_new_nchw) {
+        Scope s(h, st, FFR_KC_LAYOUT, 0, 8.0 * N * 49 * 512);
+        HIPCK(h, launch_nhwc_to_nchw(w.m512c, 512, feat_new_nchw, N, 49, 512, st));
+    }
+    return FFR_OK;
+}
+
+int ffr_embed(ffr_handle* h, const float* x, int N, float* f_new, float* f, void* stream) {
+    RC(check_fwd(h, true, true, N));
+    if (!x || !f_new) return fail(h, FFR_ERR_ARG, "x / f_new is null");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N, 112, 112, &w));
+    RC(run_encoder(h, w, x, N, 112, 112, w.X, f, st));
+    return run_recnet(h, w, N, f_new, nullptr, st);
+}
+
+int ffr_cosine_scores(ffr_handle* h, const float* a, const float* b, int n, int dim, float* score, void* stream) {
+    RC(check_fwd(h, false, false, n));
+    if (!a || !b || !score || dim <= 0) return fail(h, FFR_ERR_ARG, "ffr_cosine_scores: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Scope s(h, st, FFR_KC_SCORE, 6.0 * n * dim, 8.0 * n * dim);
+    HIPCK(h, launch_cosine(a, b, n, dim, score, st));
+    return FFR_OK;
+}
+
+int ffr_profile_enable(ffr_handle* h, int on) {
+    if (!h) return fail(nullptr, FFR_ERR_ARG, "null handle");
+    h->prof = on != 0;
+    return FFR_OK;
+}
+
+int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
+    if (!h || !out) return fail(h, FFR_ERR_ARG, "ffr_profile_read: bad arguments");
+    for (int i = 0; i < FFR_KC_COUNT; ++i) out[i] = ffr_kclass_stat{0, 0.0, 0.0, 0.0};
+    for (auto& r : h->prof_log) {
+        HIPCK(h, hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIPCK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+        out[r.kc].launches += 1;
+        out[r.kc].ms += ms;
+        out[r.kc].flops += r.flops;
+        out[r.kc].bytes += r.bytes;
+        h->ev_pool.push_back(r.e0);
+        h->ev_pool.push_back(r.e1);
+    }
+    h->prof_log.clear();
+    return FFR_OK;
+}
+
+int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream) {
+    if (!d) return fail(h, FFR_ERR_ARG, "desc is null");
+    RC(check_fwd(h, false, false, d->N));
+    if (!d->x || !d->w || !d->bias || !d->out) return fail(h, FFR_ERR_ARG, "ffr_op_conv: null tensor");
+    if (d->cin_pad % 32 || d->cout_pad % 64 || d->cin_pad <= 0) return fail(h, FFR_ERR_ARG, "ffr_op_conv: bad padding");
+    Work w;
+    RC(ensure_arena(h, d->N > 8 ? d->N : 8, 112, 112, &w));
+    ConvW L;
+    L.cin = L.cin_pad = d->cin_pad; L.cout = d->cout_store; L.cout_pad = d->cout_pad; L.R = d->R; L.S = d->S;
+    L.stride = d->stride; L.pad = d->pad; L.pad_mode = d->pad_mode; L.border = d->border_bias;
+    L.w = (float*)d->w; L.bias = (float*)d->bias; L.slope = (float*)d->slope;
+    ConvCall c{};
+    c.x = d->x; c.N = d->N; c.H = d->H; c.W = d->W; c.in_pitch = d->in_pitch; c.resid = d->resid; c.res_pitch = d->res_pitch;
+    c.out = d->out; c.out_pitch = d->out_pitch; c.out_coff = d->out_coff; c.cout_store = d->cout_store; c.flags = d->flags;
+    c.tile = d->tile; c.splitk = d->splitk; c.partial = w.partial; c.partial_cap = w.partial_cap;
+    return run_conv(h, L, c, (hipStream_t)stream);
+}
+
+int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, int n_blocks, float* out, void* stream) {
+    RC(check_fwd(h, true, false, N));
+    if (!x || !out || n_blocks < 0 || n_blocks > 24) return fail(h, FFR_ERR_ARG, "ffr_encoder_trunk_nhwc: bad arguments");
+    if (H < 32 || W < 32 || (H & 15) || (W & 15)) return fail(h, FFR_ERR_ARG, "H and W must be multiples of 16, >= 32");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N, H, W, &w));
+    float* t; int oh, ow, oc;
+    RC(run_trunk(h, w, x, N, H, W, n_blocks, st, &t, &oh, &ow, &oc));
+    HIPCK(h, hipMemcpyAsync(out, t, (size_t)N * oh * ow * oc * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FFR_OK;
+}
+
+int ffr_recnet_debug(ffr_handle* h, const float* featmap_nchw, int N, float* ss_space, float* M_space, float* feat_space,
+                     float* feat_channel_raw, float* feat_channel, void* stream) {
+    RC(check_fwd(h, false, true, N));
+    if (!featmap_nchw) return fail(h, FFR_ERR_ARG, "featmap is null");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N, 112, 112, &w));
+    HIPCK(h, launch_nchw_to_nhwc(featmap_nchw, w.X, 512, N, 49, 512, st));
+    RecDebug d{ss_space, M_space, feat_space, feat_channel_raw, feat_channel};
+    return run_recnet(h, w, N, nullptr, &d, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal launcher declarations shared by the kernel translation units and the
+// engine.  Everything here is fp32, NHWC ("pixel-major, channel-minor") unless a
+// name says nchw.  Launchers only enqueue work on `stream`; they return hipError_t.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffr {
+
+// ---- implicit-GEMM convolution (igemm.hip) -----------------------------------------
+// out[m][n] = epilogue( sum_k A[m][k] * Wp[n][k] ),  m = (img, ho, wo), k = (r, s, ci)
+struct IgemmArgs {
+    const float* x;       // [N,H,W,in_pitch]
+    const float* w;       // [cout_pad][KK] packed, KK = R*S*cin_pad
+    const float* bias;    // [n_cls][cout_pad]
+    const float* slope;   // [cout_pad] or null
+    const float* resid;   // [M][res_pitch] or null
+    float* out;           // [M][out_pitch] (+out_coff)
+    const float* zero;    // >= 128 B of zeros (source of zero-padded taps)
+    float* partial;       // split-K slabs [splits][M][cout_pad], or null
+    int N, H, W, Ho, Wo, in_pitch, cin_pad, R, S, stride, pad, pad_mode;
+    int M, KK, nkt, kt_per_split, splits;
+    int cout_pad, cout_store, out_pitch, out_coff, res_pitch;
+    int border_bias, flags;      // flags bit0: sigmoid at the end
+    int mtiles, ntiles;
+};
+enum { IGEMM_TILE_128x128 = 1, IGEMM_TILE_128x64 = 2, IGEMM_TILE_64x64 = 3, IGEMM_TILE_256x64 = 4,
+       IGEMM_NTILES = 4 };
+void igemm_tile_shape(int tile, int* bm, int* bn);
+hipError_t igemm_init();   // raises the dynamic-LDS limit of the instantiations
+hipError_t launch_igemm(const IgemmArgs& a, int tile, hipStream_t stream);
+// sums split-K slabs and applies the (non-border) epilogue of `a`
+hipError_t launch_splitk_reduce(const IgemmArgs& a, hipStream_t stream);
+
+// ---- trunk elementwise (elementwise.hip) -------------------------------------------
+// stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded
+hipError_t launch_stem(const float* x_nchw, const float* w27x64, const float* bias, const float* slope,
+                       float* out, int N, int H, int W, hipStream_t stream);
+// SE: scale[n][c] = sigmoid(fc2(relu(fc1(mean_hw res[n]))))   fc1 [C/16][C], fc2 [C][C/16]
+hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, const float* fc2,
+                     float* scale, hipStream_t stream);
+// out[n,ho,wo,c] = res*scale[n,c] + (sc ? sc[n,ho,wo,c] : x[n,ho*stride,wo*stride,c])
+hipError_t launch_combine(const float* res, const float* scale, const float* sc, const float* x,
+                          float* out, int N, int Ho, int Wo, int C, int stride, hipStream_t stream);
+// y[m][c] = x[m][c]*s[c] + t[c]    (Backbone.bn on the trunk output)
+hipError_t launch_affine(const float* x, const float* s, const float* t, float* y, int M, int C,
+                         hipStream_t stream);
+// f[n][:] = l2norm( sum_splits partial[s][n][:] + bias )   (C = 512)
+hipError_t launch_head_finish(const float* partial, int splits, int N, int C, const float* bias,
+                              float* f, hipStream_t stream);
+// layout: [N,P,C](pitch) <-> [N,C,P]
+hipError_t launch_nhwc_to_nchw(const float* in, int in_pitch, float* out, int N, int P, int C,
+                               hipStream_t stream);
+hipError_t launch_nchw_to_nhwc(const float* in, float* out, int out_pitch, int N, int P, int C,
+                               hipStream_t stream);
+// copy rows [M][C] into channel slice [coff, coff+C) of a [M][pitch] buffer
+hipError_t launch_copy_slice(const float* in, float* out, int M, int C, int pitch, int coff,
+                             hipStream_t stream);
+hipError_t launch_cosine(const float* a, const float* b, int n, int dim, float* score,
+                         hipStream_t stream);
+
+// ---- RecNet operators (recnet_ops.hip) ---------------------------------------------
+// ss_space of models/recnet.py:226-236 for X[N,49,512]; writes bufS[n,j,512+i] = ss[i][j],
+// zeros in channels [561,576), optional dense copy ss_out[N,49,49]
+hipError_t launch_selfsim_space(const float* X, float* bufS, int pitchS, float* ss_out, int N,
+                                hipStream_t stream);
+struct ChannelPathWeights {   // device pointers, see engine.cpp pack_recnet()
+    const float* w1a;   // [32][49]   Conv4Channel.0.weight[:, :49]
+    const float* w1b;   // [32][512]  Conv4Channel.0.weight[:, 49:]
+    const float* b1;    // [32]
+    const float* a1;    // [512] PReLU slopes (per row c)
+    const float* A2;    // [32][32]  = W3*W2      (Conv4Channel.3 o Conv4Channel.2)
+    const float* d2;    // [32]
+    const float* a4;    // [512]
+    const float* A3;    // [32][32]  = W6*W5
+    const float* d3;    // [32]
+    const float* a7;    // [512]
+    const float* w8;    // [512][32] Conv4Channel.8.weight
+    const float* b8;    // [512]
+};
+// feat_channel_raw[c][p] = sum_c' sigmoid(Conv4Channel(..))[c][c'] X[c'][p]; written to
+// bufF[n,p,512+c] and W-flipped to bufF[n,flip(p),c]  (bufF pitch 1024)
+hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF,
+                               int N, hipStream_t stream);
+// feat_space: out[n,j,c] = sum_i ms[n,j,i] * X[n,i,c]   (ms pitch = ms_pitch, out pitch/coff)
+hipError_t launch_space_apply(const float* X, const float* ms, int ms_pitch, float* out, int out_pitch,
+                              int out_coff, int N, hipStream_t stream);
+// f_new[n][c] = mean_p feat[n,p,c]
+hipError_t launch_avgpool49(const float* feat, float* f_new, int N, int C, hipStream_t stream);
+
+}  // namespace ffr

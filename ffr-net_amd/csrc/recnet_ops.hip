@@ -1,0 +1,279 @@
+// RecNet operators that are not convolutions (reference models/recnet.py:220-236,
+// 372-386, 398-423): self-similarity, the channel-attention row-MLP fused with the
+// M_channel @ X product, the spatial rectification product, the 7x7 average pool.
+// One workgroup per image; X = featmap as [49 positions][512 channels] (NHWC).
+#include "ffr_kernels.h"
+
+namespace ffr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------
+// ss_space[i][j] = <X_i, X_j> / (max(|X_i|,1e-12) * max(|X_j|,1e-12))   (recnet.py:220-231)
+// Gram accumulated over 4 channel chunks of 128 staged in LDS ([49][129], conflict-free
+// for row-varying reads); the diagonal gives the norms.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_selfsim_space(const float* __restrict__ X, float* __restrict__ bufS,
+                                                      int pitchS, float* __restrict__ ss_out) {
+    __shared__ float xs[49 * 129];
+    __shared__ float gram[49 * 49];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* Xn = X + (size_t)n * 49 * 512;
+    float acc[10];
+    int oi[10], oj[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        int o = tid + 256 * t;
+        if (o > 2400) o = 2400;
+        oi[t] = o / 49;
+        oj[t] = o - oi[t] * 49;
+        acc[t] = 0.f;
+    }
+    for (int c0 = 0; c0 < 512; c0 += 128) {
+        __syncthreads();
+        for (int e = tid; e < 49 * 128; e += 256) {
+            const int p = e >> 7, c = e & 127;
+            xs[p * 129 + c] = Xn[p * 512 + c0 + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const float* a = xs + oi[t] * 129;
+            const float* b = xs + oj[t] * 129;
+            float s = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < 128; ++c) s += a[c] * b[c];
+            acc[t] += s;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+        const int o = tid + 256 * t;
+        if (o <= 2400) gram[o] = acc[t];
+    }
+    __syncthreads();
+    for (int o = tid; o < 2401; o += 256) {
+        const int i = o / 49, j = o - i * 49;
+        const float ni = fmaxf(sqrtf(gram[i * 49 + i]), 1e-12f);
+        const float nj = fmaxf(sqrtf(gram[j * 49 + j]), 1e-12f);
+        const float v = gram[o] / (ni * nj);
+        // ss_space.view(N, 49, 7, 7): channel = i, position = j  ->  NHWC [n][j][512 + i]
+        bufS[((size_t)n * 49 + j) * pitchS + 512 + i] = v;
+        if (ss_out) ss_out[(size_t)n * 2401 + o] = v;
+    }
+    const int npad = pitchS - 561;
+    for (int e = tid; e < 49 * npad; e += 256) {
+        const int j = e / npad, c = e - j * npad;
+        bufS[((size_t)n * 49 + j) * pitchS + 561 + c] = 0.f;
+    }
+}
+
+hipError_t launch_selfsim_space(const float* X, float* bufS, int pitchS, float* ss_out, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(k_selfsim_space, dim3(N), dim3(256), 0, stream, X, bufS, pitchS, ss_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Channel path, one workgroup (256 threads, rows c and c+256 per thread) per image.
+//   ss_channel = Gram of channel vectors normalised over the 49 positions (recnet.py:232)
+//   channelF_cat = [X_c (49) | ss_channel_c (512)]                        (recnet.py:402)
+//   M_channel = sigmoid(Conv4Channel(channelF_cat))  [512x512]            (recnet.py:372-386,406)
+//   feat_channel = M_channel @ X                                          (recnet.py:410)
+// Re-association used (exact algebra, fp32 rounding only):
+//   * the 512-wide ss_channel part of Linear(561,32) is W1b * Xhat^T Xhat_c =
+//     (Xhat_c . G) with G[p][j] = sum_c' Xhat[p][c'] W1b[j][c'], so ss_channel (268 MB at
+//     batch 256) is never formed;
+//   * Linear(32,512) followed by Linear(512,32) with nothing between is one 32x32 affine
+//     (A2,d2 / A3,d3, folded on the host);
+//   * M_channel rows are produced one column c' at a time and consumed at once by the
+//     running product with X, so M_channel (268 MB) is never stored either.
+// ---------------------------------------------------------------------------------------
+#define XT_LD 52
+__global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ X, const ChannelPathWeights w,
+                                                     const float* __restrict__ w1bT, float* __restrict__ bufF,
+                                                     int pitchF) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* XT = sm;                       // [512][52]  X transposed: channel-major
+    float* inv = XT + 512 * XT_LD;        // [512] 1/max(|X_c|,eps)
+    float* G = inv + 512;                 // [49][32]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* Xn = X + (size_t)n * 49 * 512;
+    const int c0 = tid, c1 = tid + 256;
+
+    {   // P1: transpose into LDS + channel norms
+        float s0 = 0.f, s1 = 0.f;
+        for (int p = 0; p < 49; ++p) {
+            const float v0 = Xn[p * 512 + c0], v1 = Xn[p * 512 + c1];
+            XT[c0 * XT_LD + p] = v0;
+            XT[c1 * XT_LD + p] = v1;
+            s0 += v0 * v0;
+            s1 += v1 * v1;
+        }
+        for (int p = 49; p < XT_LD; ++p) { XT[c0 * XT_LD + p] = 0.f; XT[c1 * XT_LD + p] = 0.f; }
+        inv[c0] = 1.0f / fmaxf(sqrtf(s0), 1e-12f);
+        inv[c1] = 1.0f / fmaxf(sqrtf(s1), 1e-12f);
+    }
+    __syncthreads();
+    // P2: G[p][j] = sum_c Xhat[p][c] * W1b[j][c]   (w1bT = [512][32])
+    for (int o = tid; o < 49 * 32; o += 256) {
+        const int p = o >> 5, j = o & 31;
+        float s = 0.f;
+        for (int c = 0; c < 512; ++c) s += XT[c * XT_LD + p] * inv[c] * w1bT[c * 32 + j];
+        G[o] = s;
+    }
+    __syncthreads();
+    // P3: h[j] = b1[j] + sum_p X[p][c] * (W1a[j][p] + inv_c * G[p][j])
+    float h0[32], h1[32];
+    const float i0 = inv[c0], i1 = inv[c1];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { h0[j] = w.b1[j]; h1[j] = w.b1[j]; }
+    for (int p = 0; p < 49; ++p) {
+        const float x0 = XT[c0 * XT_LD + p], x1 = XT[c1 * XT_LD + p];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float wa = w.w1a[j * 49 + p], g = G[p * 32 + j];
+            h0[j] += x0 * (wa + i0 * g);
+            h1[j] += x1 * (wa + i1 * g);
+        }
+    }
+    // P4: PReLU (slope per row c), two folded 32x32 affines with PReLU after each
+    {
+        const float s0 = w.a1[c0], s1 = w.a1[c1];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            h0[j] = h0[j] >= 0.f ? h0[j] : h0[j] * s0;
+            h1[j] = h1[j] >= 0.f ? h1[j] : h1[j] * s1;
+        }
+    }
+#pragma unroll 1
+    for (int layer = 0; layer < 2; ++layer) {
+        const float* A = layer == 0 ? w.A2 : w.A3;
+        const float* d = layer == 0 ? w.d2 : w.d3;
+        const float* sl = layer == 0 ? w.a4 : w.a7;
+        const float s0 = sl[c0], s1 = sl[c1];
+        float t0[32], t1[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            float u0 = d[j], u1 = d[j];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float a = A[j * 32 + i];
+                u0 += a * h0[i];
+                u1 += a * h1[i];
+            }
+            t0[j] = u0 >= 0.f ? u0 : u0 * s0;
+            t1[j] = u1 >= 0.f ? u1 : u1 * s1;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { h0[j] = t0[j]; h1[j] = t1[j]; }
+    }
+    // P5: for every column c': m = sigmoid(w8[c'] . h + b8[c']);  acc[p] += m * X[p][c']
+    float acc0[XT_LD], acc1[XT_LD];
+#pragma unroll
+    for (int p = 0; p < XT_LD; ++p) { acc0[p] = 0.f; acc1[p] = 0.f; }
+#pragma unroll 1
+    for (int cp = 0; cp < 512; ++cp) {
+        float z0 = w.b8[cp], z1 = z0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float wv = w.w8[cp * 32 + i];
+            z0 += wv * h0[i];
+            z1 += wv * h1[i];
+        }
+        const float m0 = 1.0f / (1.0f + __expf(-z0));
+        const float m1 = 1.0f / (1.0f + __expf(-z1));
+        const f32x4* xr = reinterpret_cast<const f32x4*>(XT + cp * XT_LD);
+#pragma unroll
+        for (int q = 0; q < XT_LD / 4; ++q) {
+            const f32x4 xv = xr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0[q * 4 + e] += m0 * xv[e];
+                acc1[q * 4 + e] += m1 * xv[e];
+            }
+        }
+    }
+    // P6: feat_channel at channels [512,1024), its W-flip (torch.flip(.,[3])) at [0,512)
+    float* Fn = bufF + (size_t)n * 49 * pitchF;
+#pragma unroll
+    for (int p = 0; p < 49; ++p) {
+        const int pf = (p / 7) * 7 + (6 - p % 7);
+        Fn[p * pitchF + 512 + c0] = acc0[p];
+        Fn[p * pitchF + 512 + c1] = acc1[p];
+        Fn[pf * pitchF + c0] = acc0[p];
+        Fn[pf * pitchF + c1] = acc1[p];
+    }
+}
+
+// w.w1b is passed TRANSPOSED ([512][32]) by the engine
+hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF, int N,
+                               hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t lds = (size_t)(512 * XT_LD + 512 + 49 * 32) * 4;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_channel_path, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_channel_path, dim3(N), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// feat_space = X @ M_space (recnet.py:409):  out[n][j][c] = sum_i ms[n][j][i] * X[n][i][c]
+// 512 threads = one channel each, X column in registers, ms rows broadcast from LDS.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_space_apply(const float* __restrict__ X, const float* __restrict__ ms,
+                                                    int ms_pitch, float* __restrict__ out, int out_pitch,
+                                                    int out_coff) {
+    __shared__ __attribute__((aligned(16))) float s_ms[49 * 52];
+    const int n = blockIdx.x, c = threadIdx.x;
+    for (int e = c; e < 49 * 52; e += 512) {
+        const int j = e / 52, i = e - j * 52;
+        s_ms[e] = i < 49 ? ms[((size_t)n * 49 + j) * ms_pitch + i] : 0.f;
+    }
+    float x[52];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) x[i] = X[((size_t)n * 49 + i) * 512 + c];
+    x[49] = x[50] = x[51] = 0.f;
+    __syncthreads();
+    for (int j = 0; j < 49; ++j) {
+        const f32x4* mr = reinterpret_cast<const f32x4*>(s_ms + j * 52);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 13; ++q) {
+            const f32x4 mv = mr[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += mv[e] * x[q * 4 + e];
+        }
+        out[((size_t)n * 49 + j) * out_pitch + out_coff + c] = s;
+    }
+}
+
+hipError_t launch_space_apply(const float* X, const float* ms, int ms_pitch, float* out, int out_pitch,
+                              int out_coff, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(k_space_apply, dim3(N), dim3(512), 0, stream, X, ms, ms_pitch, out, out_pitch, out_coff);
+    return hipGetLastError();
+}
+
+// pool5_7x7 (recnet.py:395,423)
+__global__ __launch_bounds__(256) void k_avgpool49(const float* __restrict__ feat, float* __restrict__ f_new,
+                                                  int C, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long n = idx / C;
+    const int c = (int)(idx - n * C);
+    float s = 0.f;
+#pragma unroll 7
+    for (int p = 0; p < 49; ++p) s += feat[(n * 49 + p) * C + c];
+    f_new[idx] = s * (1.0f / 49.0f);
+}
+
+hipError_t launch_avgpool49(const float* feat, float* f_new, int N, int C, hipStream_t stream) {
+    const long long total = (long long)N * C;
+    hipLaunchKernelGGL(k_avgpool49, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feat, f_new, C, total);
+    return hipGetLastError();
+}
+
+}  // namespace ffr

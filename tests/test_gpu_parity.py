@@ -1,0 +1,231 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed
+goldens.  Needs a real MI355X: `python -m pytest tests -m gpu`.
+
+Tolerance (BASELINE.json north_star): max-abs-err / max-abs-ref <= 1e-3 per output
+tensor, fp32.  Single operators are held to 2e-5 (pure fp32 re-association)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import ffrnet_amd
+from ffrnet_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import ffr_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+OP_TOL = 2e-5
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope='module')
+def engine(state_dicts):
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    sd_e, sd_r = state_dicts
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    eng.load_recnet(sd_r)
+    return eng
+
+
+def pack_w(w, cin_pad, cout_pad):
+    cout, cin, R, S = w.shape
+    p = torch.zeros(cout_pad, R, S, cin_pad)
+    p[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+    return p.reshape(cout_pad, -1).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, cin, cout, R, stride, pad, mode, prelu, resid, sigmoid, tile, splitk
+    (2, 14, 14, 64, 64, 3, 1, 1, 0, True, False, False, 0, 0),
+    (3, 14, 14, 64, 128, 3, 2, 1, 0, False, False, False, 1, 0),
+    (2, 28, 20, 32, 64, 3, 1, 1, 0, True, True, False, 2, 0),
+    (2, 28, 28, 64, 128, 1, 2, 0, 0, False, False, False, 3, 0),
+    (5, 7, 7, 96, 49, 3, 1, 1, 1, True, True, True, 0, 0),
+    (4, 7, 7, 561, 256, 3, 1, 1, 1, True, False, False, 0, 0),
+    (2, 7, 7, 128, 64, 3, 1, 1, 1, True, False, False, 3, 4),
+    (2, 16, 16, 64, 64, 3, 1, 1, 0, True, False, False, 4, 0),
+    (9, 1, 1, 25088, 512, 1, 1, 0, 0, False, False, False, 0, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_operator(engine, case):
+    N, H, W, cin, cout, R, stride, pad, mode, prelu, resid, sig, tile, splitk = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    cin_pad = (cin + 31) // 32 * 32
+    cout_pad = (cout + 63) // 64 * 64
+    in_pitch = cin_pad + 32
+    x = torch.randn(N, H, W, in_pitch, generator=g)
+    x[..., cin:cin_pad] = 0
+    w = torch.randn(cout, cin, R, R, generator=g) / (cin * R * R) ** 0.5
+    bias = torch.zeros(cout_pad)
+    bias[:cout] = torch.randn(cout, generator=g) * 0.1
+    slope = torch.zeros(cout_pad)
+    slope[:cout] = torch.rand(cout, generator=g) * 0.3 + 0.1
+    xin = x[..., :cin].permute(0, 3, 1, 2)
+    if mode == 1:
+        ref = F.conv2d(F.pad(xin, (pad,) * 4, mode='reflect'), w, None, stride)
+    else:
+        ref = F.conv2d(xin, w, None, stride, pad)
+    ref = ref + bias[:cout].view(1, -1, 1, 1)
+    if prelu:
+        ref = F.prelu(ref, slope[:cout])
+    Ho, Wo = ref.shape[2:]
+    res_pitch = cout_pad + 64
+    r = torch.randn(N, Ho, Wo, res_pitch, generator=g)
+    if resid:
+        ref = ref + r[..., :cout].permute(0, 3, 1, 2)
+    if sig:
+        ref = torch.sigmoid(ref)
+    out_pitch, out_coff = cout_pad + 96, 32
+    out = torch.full((N, Ho, Wo, out_pitch), -7.0).cuda()
+    engine.op_conv(x=x.cuda(), N=N, H=H, W=W, in_pitch=in_pitch, cin_pad=cin_pad,
+                   w=pack_w(w, cin_pad, cout_pad).cuda(), bias=bias.cuda(),
+                   slope=slope.cuda() if prelu else None,
+                   resid=r.cuda() if resid else None, res_pitch=res_pitch,
+                   out=out, out_pitch=out_pitch, out_coff=out_coff, cout_store=cout, cout_pad=cout_pad,
+                   R=R, S=R, stride=stride, pad=pad, pad_mode=mode, border_bias=0,
+                   flags=1 if sig else 0, tile=tile, splitk=splitk)
+    torch.cuda.synchronize()
+    got = out[..., out_coff:out_coff + cout].permute(0, 3, 1, 2).cpu()
+    assert rel(got, ref) < OP_TOL
+    # nothing outside the channel slice was touched
+    assert (out[..., :out_coff] == -7.0).all() and (out[..., out_coff + cout:] == -7.0).all()
+
+
+def test_trunk_stage_taps(engine, state_dicts, golden_dir):
+    sd_e, _ = state_dicts
+    x = synth.synth_images(8, 112, 112, seed=123)[:2]
+    taps = {}
+    with torch.no_grad():
+        O.encoder_trunk(sd_e, x, 24, taps)
+    g2 = np.load(os.path.join(golden_dir, 'g2_stage_taps.npz'))
+    xd = x.cuda()
+    for nb, name in [(0, 'input_layer')] + [(i + 1, 'body.%d' % i) for i in (0, 2, 3, 6, 7, 20, 21, 23)]:
+        got = engine.encoder_trunk_nhwc(xd, nb).permute(0, 3, 1, 2).cpu()
+        assert rel(got, taps[name]) < TOL, name
+        flat = got[0].reshape(-1)
+        step = max(1, flat.numel() // 256)
+        assert np.abs(flat[::step][:256].numpy() - g2[name + '.samples']).max() \
+            < TOL * float(g2[name + '.absmax']), name
+        if (name + '.full') in g2:
+            assert rel(got[0], torch.from_numpy(g2[name + '.full'])) < TOL
+
+
+def test_config1_embeddings_vs_golden(engine, golden_dir):
+    """BASELINE config 1 inputs through the HIP path vs the reference's own outputs."""
+    g = np.load(os.path.join(golden_dir, 'g1_config1.npz'))
+    x = synth.synth_images(8, 112, 112, seed=123).cuda()
+    featmap, f = engine.encoder_forward(x)
+    f_new, feat_new = engine.recnet_forward(featmap)
+    f_new2, f2 = engine.embed(x)
+    torch.cuda.synchronize()
+    assert rel(f, torch.from_numpy(g['f'])) < TOL
+    assert rel(f_new, torch.from_numpy(g['f_new'])) < TOL
+    assert rel(featmap[0], torch.from_numpy(g['featmap0'])) < TOL
+    assert rel(feat_new[0], torch.from_numpy(g['feat_new0'])) < TOL
+    assert rel(f_new2, torch.from_numpy(g['f_new'])) < TOL
+    assert rel(f2, torch.from_numpy(g['f'])) < TOL
+    # per-row relative L2
+    for a, b in ((f_new.cpu(), torch.from_numpy(g['f_new'])), (f.cpu(), torch.from_numpy(g['f']))):
+        assert (((a - b).norm(dim=1) / b.norm(dim=1)).max().item()) < TOL
+
+
+def test_recnet_internals_vs_golden(engine, golden_dir):
+    g1 = np.load(os.path.join(golden_dir, 'g1_config1.npz'))
+    g3 = np.load(os.path.join(golden_dir, 'g3_recnet_internals.npz'))
+    fm = torch.from_numpy(g1['featmap0'])[None].cuda()
+    d = engine.recnet_debug(fm)
+    torch.cuda.synchronize()
+    assert rel(d['ss_space'][0], torch.from_numpy(g3['ss_space0'])) < TOL
+    assert rel(d['M_space'][0], torch.from_numpy(g3['M_space0'])) < TOL
+    assert rel(d['feat_space'][0], torch.from_numpy(g3['feat_space0'])) < TOL
+    assert rel(d['feat_channel_raw'][0], torch.from_numpy(g3['feat_channel_raw0'])) < TOL
+    assert rel(d['feat_channel'][0], torch.from_numpy(g3['feat_channel0'])) < TOL
+
+
+def test_trunk_112x96(engine, golden_dir):
+    """The BASELINE.json '112x96' label: only the trunk exists at that size."""
+    g = np.load(os.path.join(golden_dir, 'g6_trunk_112x96.npz'))
+    x = synth.synth_images(2, 112, 96, seed=125).cuda()
+    featmap, f = engine.encoder_forward(x, want_f=False)
+    assert f is None and list(featmap.shape) == [2, 512, 7, 6]
+    assert rel(featmap[0], torch.from_numpy(g['featmap0'])) < TOL
+    with open(os.path.join(golden_dir, 'g7_112x96_errors.json')) as fh:
+        msgs = json.load(fh)
+    with pytest.raises(RuntimeError) as ei:
+        engine.encoder_forward(x)
+    assert '21504 and 25088x512' in str(ei.value) and '21504 and 25088x512' in msgs['encoder']
+    with pytest.raises(RuntimeError):
+        engine.recnet_forward(featmap)
+
+
+@pytest.mark.parametrize('n', [1, 3, 33])
+def test_ragged_batches_vs_oracle(engine, state_dicts, n):
+    sd_e, sd_r = state_dicts
+    x = synth.synth_images(n, seed=500 + n)
+    f_new, f = engine.embed(x.cuda())
+    rf_new, rf = O.embed(sd_e, sd_r, x)
+    assert rel(f_new, rf_new) < TOL and rel(f, rf) < TOL
+
+
+def test_batch_independence_full_size(engine):
+    """BASELINE batch 256: images are independent units, so image i of the batch must
+    equal image i embedded in a batch of 8 (size-independent property; the oracle is
+    too slow for 256 images in a unit test)."""
+    x = synth.synth_images(256, seed=124).cuda()
+    f_new, f = engine.embed(x)
+    idx = [0, 1, 100, 128, 200, 253, 254, 255]
+    g_new, g = engine.embed(x[idx].contiguous())
+    assert rel(f_new[idx], g_new) < 1e-5 and rel(f[idx], g) < 1e-5
+    assert torch.isfinite(f_new).all() and torch.isfinite(f).all()
+    assert ((f.norm(dim=1) - 1).abs() < 1e-4).all()
+
+
+def test_module_shells_drop_in(state_dicts, golden_dir):
+    """models/trainer.py:98-113 clone_model flow through the nn.Module shells."""
+    sd_e, sd_r = state_dicts
+    enc = ffrnet_amd.Backbone(num_layers=50, drop_ratio=0.6, mode='ir_se')
+    rec = ffrnet_amd.RecNet(norm_type='bn', relu_type='prelu')
+    enc.load_state_dict(sd_e)
+    rec.load_state_dict(sd_r)
+    enc2 = ffrnet_amd.Backbone(num_layers=50, drop_ratio=0.6, mode='ir_se')
+    enc2.load_state_dict(enc.state_dict())
+    enc2.to('cuda').eval()
+    rec.to('cuda').eval()
+    g = np.load(os.path.join(golden_dir, 'g1_config1.npz'))
+    x = synth.synth_images(8, 112, 112, seed=123).cuda()
+    with torch.no_grad():
+        feat_map, f = enc2(x)
+        f_new, _ = rec(feat_map)
+    assert rel(f, torch.from_numpy(g['f'])) < TOL
+    assert rel(f_new, torch.from_numpy(g['f_new'])) < TOL
+    with pytest.raises(RuntimeError):
+        enc2(x.cpu())
+    enc2.train()
+    with pytest.raises(NotImplementedError):
+        enc2(x)
+
+
+def test_calculate_distance_and_accuracy(engine, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g4_calculate_distance.npz'))
+    i1, i2, lab = synth.synth_pairs(16, seed=7, block=8)
+    loader = [dict(img1=i1[s:s + 8].cuda(), img2=i2[s:s + 8].cuda(), label=lab[s:s + 8],
+                   idx=torch.arange(s, s + 8)) for s in (0, 8)]
+    pn, p = ffrnet_amd.lfw.calculate_distance(loader, engine.embed, score_fn=engine.cosine_scores)
+    assert np.abs(pn[:, 0] - g['pred_new'][:, 0]).max() < 1e-4
+    assert np.abs(p[:, 0] - g['pred'][:, 0]).max() < 1e-4
+    assert np.array_equal(pn[:, 1:], g['pred_new'][:, 1:])
