@@ -1,0 +1,143 @@
+"""CPU-only checks of the host side: the state_dict contract of the shells, the C-ABI
+library's exported symbols (no compute without a GPU), loud failure without the native
+path, and the sharded verification harness on 2 gloo ranks."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import ffrnet_amd
+from ffrnet_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_key_contract(specs):
+    """402 / 121 entries, same names, order and shapes as the reference modules (G0)."""
+    enc = ffrnet_amd.Backbone(num_layers=50, drop_ratio=0.6, mode='ir_se')
+    rec = ffrnet_amd.RecNet(channel=512, shape=7, norm_type='bn', relu_type='prelu')
+    for mod, key in ((enc, 'encoder'), (rec, 'recnet')):
+        sd = mod.state_dict()
+        assert list(sd.keys()) == list(specs[key].keys())
+        for k, v in sd.items():
+            assert list(v.shape) == specs[key][k], k
+    assert len(specs['encoder']) == 402 and len(specs['recnet']) == 121
+    # strict load of a reference-shaped state_dict, clone flow of models/trainer.py:98-113
+    sd_e = ffrnet_amd.synth.synth_state_dict(specs['encoder'])
+    enc.load_state_dict(sd_e)
+    enc2 = ffrnet_amd.Backbone(50, 0.6, 'ir_se')
+    enc2.load_state_dict(enc.state_dict())
+    assert torch.equal(enc2.state_dict()['body.3.shortcut_layer.0.weight'],
+                       sd_e['body.3.shortcut_layer.0.weight'])
+
+
+def test_unsupported_constructor_arguments():
+    with pytest.raises(NotImplementedError):
+        ffrnet_amd.Backbone(100, 0.6, 'ir_se')
+    with pytest.raises(NotImplementedError):
+        ffrnet_amd.RecNet(norm_type='in')
+    with pytest.raises(AssertionError):
+        ffrnet_amd.Backbone(34, 0.6, 'ir_se')
+
+
+def test_no_cpu_fallback():
+    """The product fails loudly off-GPU: no oracle, no stock-torch path."""
+    enc = ffrnet_amd.Backbone(50, 0.6, 'ir_se').eval()
+    rec = ffrnet_amd.RecNet().eval()
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, 3, 112, 112))
+    with pytest.raises(RuntimeError):
+        rec(torch.zeros(1, 512, 7, 7))
+    with pytest.raises(NotImplementedError):
+        rec(torch.zeros(1, 512, 7, 7), label=torch.zeros(1))
+    src = ''
+    for fn in os.listdir(os.path.join(ROOT, 'ffr-net_amd')):
+        if fn.endswith('.py'):
+            src += open(os.path.join(ROOT, 'ffr-net_amd', fn)).read()
+    assert not re.search(r'^\s*(import|from)\s+\.*(oracle|ffr_oracle)', src, re.M)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The .so loads without a GPU and exports each function include/ffrnet.h declares."""
+    path = native.lib_path()
+    assert os.path.exists(path), 'run __graft_entry__.build() first'
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, 'include', 'ffrnet.h')).read()
+    declared = set(re.findall(r'\b(ffr_[a-z_0-9]+)\s*\(', hdr))
+    bound = {n for n, _, _ in native.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        getattr(lib, name)
+    lib.ffr_version.restype = ctypes.c_char_p
+    assert b'gfx950' in lib.ffr_version()
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p(0)
+        rc = lib.ffr_create(ctypes.byref(h), 0)
+        assert rc != 0 and not h.value          # no device -> error code, never a CPU path
+
+
+def test_shard_bounds_cover_everything():
+    for n in (1, 7, 512, 513):
+        for world in (1, 2, 8):
+            got = []
+            for r in range(world):
+                lo, hi = ffrnet_amd.lfw.shard_bounds(n, r, world)
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import ffrnet_amd
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[3]
+dist.init_process_group('gloo', rank=rank, world_size=world)
+P = torch.randn(3 * 112 * 112, 512, generator=torch.Generator().manual_seed(5)) / 100
+def embed(img):                      # stand-in embedder (host-logic test, CPU)
+    e = img.reshape(img.size(0), -1) @ P
+    return e, torch.tanh(e)
+calls = []
+def counting(img):
+    calls.append(img.size(0)); return embed(img)
+i1, i2, lab = ffrnet_amd.synth.synth_pairs(21, seed=3, block=6)
+loader = [dict(img1=i1[s:s+8], img2=i2[s:s+8], label=lab[s:s+8], idx=torch.arange(s, min(s+8, 21)))
+          for s in (0, 8, 16)]
+pn, p = ffrnet_amd.lfw.calculate_distance(loader, counting)
+np.save(sys.argv[4] + '.%%d.npy' %% rank, np.concatenate([pn, p], 1))
+print('calls', rank, calls)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_verification_two_ranks_gloo(tmp_path):
+    """world_size 2 over gloo: every rank embeds only its shard, the all-gathered result
+    equals the single-process result."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % {'root': ROOT})
+    port = str(29500 + os.getpid() % 2000)
+    out = str(tmp_path / 'res')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2', port, out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    r0, r1 = np.load(out + '.0.npy'), np.load(out + '.1.npy')
+    assert np.array_equal(r0, r1)
+    # single process reference
+    P = torch.randn(3 * 112 * 112, 512, generator=torch.Generator().manual_seed(5)) / 100
+
+    def embed(img):
+        e = img.reshape(img.size(0), -1) @ P
+        return e, torch.tanh(e)
+    i1, i2, lab = ffrnet_amd.synth.synth_pairs(21, seed=3, block=6)
+    loader = [dict(img1=i1[s:s + 8], img2=i2[s:s + 8], label=lab[s:s + 8],
+                   idx=torch.arange(s, min(s + 8, 21))) for s in (0, 8, 16)]
+    pn, p = ffrnet_amd.lfw.calculate_distance(loader, embed)
+    assert np.abs(np.concatenate([pn, p], 1) - r0).max() < 1e-5
+    assert 'calls 0 [8, 8, 6]' in logs[0] and 'calls 1 [8, 8, 4]' in logs[1]
