@@ -52,7 +52,7 @@ struct ProfRec {
 struct ffr_handle {
     int device = 0;
     std::string err;
-    float* zero = nullptr;   // 256 B zero page
+    float* zero = nullptr;   // 128 KiB zero page (source of zero-padded taps, >= any cin_pad)
     // weights
     std::vector<void*> enc_allocs, rec_allocs;
     bool enc_loaded = false, rec_loaded = false;
@@ -575,8 +575,8 @@ int ffr_create(ffr_handle** out, int device) {
     ffr_handle* h = new ffr_handle();
     h->device = device;
     void* z = nullptr;
-    if (hipMalloc(&z, 256) != hipSuccess) { delete h; return fail(nullptr, FFR_ERR_NOMEM, "hipMalloc failed"); }
-    hipMemset(z, 0, 256);
+    if (hipMalloc(&z, 131072) != hipSuccess) { delete h; return fail(nullptr, FFR_ERR_NOMEM, "hipMalloc failed"); }
+    hipMemset(z, 0, 131072);
     h->zero = (float*)z;
     hipError_t e = igemm_init();
     if (e != hipSuccess) {

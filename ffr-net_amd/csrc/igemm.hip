@@ -30,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int PAD_MODE>
 __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     // ---- per-thread staging rows -------------------------------------------------
     const int srow = tid >> 3;                              // 0..31
     const int lch = (tid & 7) ^ ((srow >> 1) & 7);          // logical 16-B chunk this lane fetches
-    int a_pix[A_PT], a_h[A_PT], a_w[A_PT];
+    int a_pix[A_PT], a_hw[A_PT];                            // pixel base, packed (h0 << 16) | (w0 & 0xffff)
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
         int m = m0 + srow + 32 * i;
@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         const int ho = rem / a.Wo;
         const int wo = rem - ho * a.Wo;
         a_pix[i] = n * a.H * a.W;
-        a_h[i] = ho * a.stride - a.pad;
-        a_w[i] = wo * a.stride - a.pad;
+        a_hw[i] = ((ho * a.stride - a.pad) << 16) | ((wo * a.stride - a.pad) & 0xffff);
     }
     if (a.border_bias && tid < BM) {
         int m = m0 + tid;
@@ -84,44 +83,55 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     const int kt_begin = split * a.kt_per_split;
     int nk = a.nkt - kt_begin;
     if (nk > a.kt_per_split) nk = a.kt_per_split;
-    int kbase = kt_begin * 32;
-    int tap = kbase / a.cin_pad;
-    int c0 = kbase - tap * a.cin_pad;
+    const int kbase0 = kt_begin * 32;
+    int tap = kbase0 / a.cin_pad;
+    int c0 = kbase0 - tap * a.cin_pad;
     int tr = tap / a.S, ts = tap - tr * a.S;
 
-    const float* wrow[B_PT];
+    // current source pointer of every staged row (advances 32 floats per K-tile; the
+    // A pointers are re-derived when the tap changes)
+    const float* a_ptr[A_PT];
+    const float* b_ptr[B_PT];
 #pragma unroll
     for (int i = 0; i < B_PT; ++i)
-        wrow[i] = a.w + (size_t)(n0 + srow + 32 * i) * a.KK + lch * 4;
+        b_ptr[i] = a.w + (size_t)(n0 + srow + 32 * i) * a.KK + kbase0 + lch * 4;
 
-    auto issue_stage = [&](int buf) {
-        float* sA = smem + buf * STAGE_FLOATS;
-        float* sB = sA + BM * 32;
+    auto set_tap = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
-            int hi = a_h[i] + tr, wi = a_w[i] + ts;
+            int hi = (a_hw[i] >> 16) + tr, wi = (int)(short)(a_hw[i] & 0xffff) + ts;
             bool ok = true;
-            if (a.pad_mode == 1) {
+            if (PAD_MODE == 1) {
                 hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi);
                 wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi);
             } else {
                 ok = ((unsigned)hi < (unsigned)a.H) && ((unsigned)wi < (unsigned)a.W);
             }
-            const float* src = ok ? a.x + (size_t)(a_pix[i] + hi * a.W + wi) * a.in_pitch + c0 + lch * 4
-                                  : a.zero + lch * 4;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (32 * i + 8 * wave) * 32), 16, 0, 0);
+            const float* src = a.x + (size_t)(a_pix[i] + hi * a.W + wi) * a.in_pitch;
+            a_ptr[i] = (ok ? src : a.zero) + c0 + lch * 4;   // the zero page is >= cin_pad floats long
         }
-#pragma unroll
-        for (int i = 0; i < B_PT; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(wrow[i] + kbase),
-                                             LDS_PTR(sB + (32 * i + 8 * wave) * 32), 16, 0, 0);
+    };
+    set_tap();
+
+    // one 16-B-per-lane LDS-DMA piece (8 rows x 128 B per wave) of the next K-tile
+    auto dma_piece = [&](int buf, int d) {
+        float* sA = smem + buf * STAGE_FLOATS;
+        if (d < A_PT) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_ptr[d]), LDS_PTR(sA + (32 * d + 8 * wave) * 32), 16, 0, 0);
+            a_ptr[d] += 32;
+        } else {
+            const int i = d - A_PT;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_ptr[i]), LDS_PTR(sA + (BM + 32 * i + 8 * wave) * 32), 16, 0, 0);
+            b_ptr[i] += 32;
         }
-        // advance to the next K-tile
-        kbase += 32;
+    };
+    // after all pieces of a K-tile are issued: move to the next tap when the channel run ends
+    auto advance_tile = [&]() {
         c0 += 32;
         if (c0 == a.cin_pad) {
             c0 = 0;
             if (++ts == a.S) { ts = 0; ++tr; }
+            set_tap();
         }
     };
 
@@ -136,31 +146,69 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     const int frow = lane & 31;
     const int fh = lane >> 5;
     const int fswz = (lane >> 1) & 7;
+    int pc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pc[q] = ((2 * q + fh) ^ fswz) * 4;
+    const int fragA = (wm * WM + frow) * 32, fragB = (BM + wn * WN + frow) * 32;
 
-    issue_stage(0);
-    for (int it = 0; it < nk; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it + 1 < nk) issue_stage((it + 1) & 1);
-        const float* sA = smem + (it & 1) * STAGE_FLOATS + (wm * WM + frow) * 32;
-        const float* sB = smem + (it & 1) * STAGE_FLOATS + (BM + wn * WN + frow) * 32;
+    constexpr int NQ = TM * TN * 4;          // MFMAs per 8-k chunk
+    constexpr int NR = TM + TN;              // fragment reads per chunk
+    constexpr int ND = A_PT + B_PT;          // DMA pieces per K-tile
+    constexpr int NDH = (ND + 1) / 2;        // ... issued in the gaps of chunks 0 and 1
+    static_assert(NR + NDH <= NQ, "fillers must fit the MFMA gaps of a chunk");
+    f32x4 af[2][TM], bf[2][TN];
+#define FFR_PIN __builtin_amdgcn_sched_barrier(0)
+
+    // fragment read r of a chunk: rows of A then rows of B, 16 B per lane (4 k values)
+    auto read_piece = [&](int slot, const float* stage, int pcv, int r) {
+        if (r < TM) af[slot][r] = *reinterpret_cast<const f32x4*>(stage + fragA + r * 32 * 32 + pcv);
+        else bf[slot][r - TM] = *reinterpret_cast<const f32x4*>(stage + fragB + (r - TM) * 32 * 32 + pcv);
+    };
+
+    // One K-tile.  Every MFMA gap (64 cycles on the SIMD's matrix pipe) carries at most ONE
+    // filler -- a fragment ds_read_b128 for the next chunk or one LDS-DMA piece of the next
+    // K-tile -- and the order is pinned (sched_barrier): an LDS-DMA costs its wave ~60 issue
+    // cycles, so 4-8 of them back to back starve the matrix pipe (measured: -10 % at 8 blocks/CU,
+    // more in the 1-block/CU tail).  The barrier that publishes tile t+1 sits in front of the
+    // LAST chunk of tile t, so the first fragments of t+1 are read under that chunk's MFMAs.
+    auto tile_body = [&]<bool LAST>(int cur) {
+        const float* stage = smem + cur * STAGE_FLOATS;
+        const float* stage_n = smem + (cur ^ 1) * STAGE_FLOATS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int pc = ((2 * q + fh) ^ fswz) * 4;
-            f32x4 af[TM], bf[TN];
+            if (q == 3 && !LAST) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                FFR_PIN;
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * 32 + pc);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * 32 + pc);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            for (int g = 0; g < NQ; ++g) {
+                const int e = g / (TM * TN), i = (g / TN) % TM, j = g % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i][e], bf[q & 1][j][e], acc[i][j], 0, 0, 0);
+                if (g < NR) {
+                    if (q < 3) read_piece((q + 1) & 1, stage, pc[q + 1], g);
+                    else if (!LAST) read_piece(0, stage_n, pc[0], g);
+                } else if (!LAST && q < 2 && (g - NR) < NDH && q * NDH + (g - NR) < ND) {
+                    dma_piece(cur ^ 1, q * NDH + (g - NR));
+                }
+                FFR_PIN;
+            }
+            if (q == 1 && !LAST) { advance_tile(); FFR_PIN; }
         }
-    }
+    };
+
+    // prologue: tile 0 -> stage 0, its first fragments -> slot 0
+#pragma unroll
+    for (int d = 0; d < ND; ++d) dma_piece(0, d);
+    advance_tile();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NR; ++r) read_piece(0, smem, pc[0], r);
+    FFR_PIN;
+    for (int it = 0; it + 1 < nk; ++it) tile_body.template operator()<false>(it & 1);
+    tile_body.template operator()<true>((nk - 1) & 1);
+#undef FFR_PIN
 
     // ---- epilogue ----------------------------------------------------------------
     const int ncol0 = n0 + wn * WN + frow;
@@ -243,17 +291,18 @@ static size_t igemm_lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * 3
 
 hipError_t igemm_init() {
     hipError_t e;
-    e = hipFuncSetAttribute((const void*)k_igemm<128, 128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)igemm_lds_bytes(128, 128));
+#define FFR_SET_LDS(BM, BN, WMM, WNN)                                                                   \
+    e = hipFuncSetAttribute((const void*)k_igemm<BM, BN, WMM, WNN, 0>,                                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)igemm_lds_bytes(BM, BN));  \
+    if (e != hipSuccess) return e;                                                                      \
+    e = hipFuncSetAttribute((const void*)k_igemm<BM, BN, WMM, WNN, 1>,                                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)igemm_lds_bytes(BM, BN));  \
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_igemm<128, 64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)igemm_lds_bytes(128, 64));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_igemm<64, 64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)igemm_lds_bytes(64, 64));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_igemm<256, 64, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)igemm_lds_bytes(256, 64));
+    FFR_SET_LDS(128, 128, 2, 2)
+    FFR_SET_LDS(128, 64, 2, 2)
+    FFR_SET_LDS(64, 64, 2, 2)
+    FFR_SET_LDS(256, 64, 4, 1)
+#undef FFR_SET_LDS
     return e;
 }
 
@@ -263,12 +312,16 @@ hipError_t launch_igemm(const IgemmArgs& a, int tile, hipStream_t stream) {
     if (!bm) return hipErrorInvalidValue;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.splits, 1);
     const size_t lds = igemm_lds_bytes(bm, bn);
+#define FFR_LAUNCH(BM, BN, WMM, WNN)                                                                      \
+    if (a.pad_mode == 1) hipLaunchKernelGGL((k_igemm<BM, BN, WMM, WNN, 1>), grid, dim3(256), lds, stream, a); \
+    else hipLaunchKernelGGL((k_igemm<BM, BN, WMM, WNN, 0>), grid, dim3(256), lds, stream, a);
     switch (tile) {
-        case IGEMM_TILE_128x128: hipLaunchKernelGGL((k_igemm<128, 128, 2, 2>), grid, dim3(256), lds, stream, a); break;
-        case IGEMM_TILE_128x64: hipLaunchKernelGGL((k_igemm<128, 64, 2, 2>), grid, dim3(256), lds, stream, a); break;
-        case IGEMM_TILE_64x64: hipLaunchKernelGGL((k_igemm<64, 64, 2, 2>), grid, dim3(256), lds, stream, a); break;
-        case IGEMM_TILE_256x64: hipLaunchKernelGGL((k_igemm<256, 64, 4, 1>), grid, dim3(256), lds, stream, a); break;
+        case IGEMM_TILE_128x128: FFR_LAUNCH(128, 128, 2, 2) break;
+        case IGEMM_TILE_128x64: FFR_LAUNCH(128, 64, 2, 2) break;
+        case IGEMM_TILE_64x64: FFR_LAUNCH(64, 64, 2, 2) break;
+        case IGEMM_TILE_256x64: FFR_LAUNCH(256, 64, 4, 1) break;
     }
+#undef FFR_LAUNCH
     return hipGetLastError();
 }
 
