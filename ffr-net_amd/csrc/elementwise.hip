@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* __restrict__ p
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int c = tid + e * 256;
-        float s = bias[c];
+        float s = bias ? bias[c] : 0.f;
         for (int k = 0; k < splits; ++k) s += partial[((size_t)k * N + n) * C + c];
         v[e] = s;
         ss += s * s;

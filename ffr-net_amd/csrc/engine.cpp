@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -65,6 +66,8 @@ struct ffr_handle {
     // workspace arena
     char* arena = nullptr;
     size_t arena_bytes = 0;
+    int* tickets = nullptr;      // stream-K arrival counters (zero between launches)
+    size_t tickets_cap = 0;
     // profiling
     bool prof = false;
     std::vector<ProfRec> prof_log;
@@ -242,44 +245,54 @@ void block_table(int cin[24], int depth[24], int stride[24]) {
 }
 
 // ---- convolution dispatch --------------------------------------------------------------
-void plan_conv(long long M, int cout_pad, int nkt, int force_tile, int force_split, int* tile, int* splits) {
-    static const double eff[IGEMM_NTILES + 1] = {0, 1.00, 1.04, 1.12, 1.02};
-    int best = 0;
-    double best_cost = 1e300;
-    for (int t = 1; t <= 3; ++t) {     // 256x64 stays opt-in (1 block/CU)
+// Tile shape and block count of one launch.
+//  * large problems (at least a quarter of a tile of K-tiles per persistent block at 128x128):
+//    persistent stream-K over 256 CUs x resident blocks, biggest tile that divides cout (tile
+//    efficiency measured on the MI355X: 128x128 > 128x64 > 64x64, profiles/r01_conv_sweep*);
+//  * small problems: 64x64 tiles; whole tiles per block when they fill 160..1024 blocks
+//    (nothing is cut), else stream-K with at least `min_units` K-tiles per block.
+void plan_conv(long long M, int cout_pad, int nkt, int force_tile, int* tile, int* nblocks, int* granule) {
+    static const int min_units = getenv("FFR_SK_MINUNITS") ? atoi(getenv("FFR_SK_MINUNITS")) : 18;
+    auto ntiles = [&](int t) {
         int bm, bn;
         igemm_tile_shape(t, &bm, &bn);
-        if (cout_pad % bn) continue;
-        const double tiles = (double)((M + bm - 1) / bm) * (cout_pad / bn);
-        const double rounds = std::ceil(tiles / 256.0);
-        const double cost = rounds * bm * bn * eff[t];
-        if (cost < best_cost) { best_cost = cost; best = t; }
-    }
+        return ((M + bm - 1) / bm) * (long long)(cout_pad / bn);
+    };
+    int best = (cout_pad % 128 == 0) ? IGEMM_TILE_128x128 : IGEMM_TILE_128x64;
+    const long long big_units = ntiles(best) * nkt;
+    const bool large = big_units / (256LL * igemm_resident_blocks(best)) >= (nkt + 3) / 4 && M >= 1024;
+    if (!large) best = IGEMM_TILE_64x64;
     if (force_tile >= 1 && force_tile <= IGEMM_NTILES) best = force_tile;
-    int bm, bn;
-    igemm_tile_shape(best, &bm, &bn);
-    const long long tiles = ((M + bm - 1) / bm) * (cout_pad / bn);
-    int sp = 1;
-    if (force_split > 0) sp = force_split;
-    else if (tiles < 128 && nkt >= 16) {
-        sp = (int)(256 / tiles);
-        if (sp > nkt / 8) sp = nkt / 8;
-        if (sp > 32) sp = 32;
-        if (sp < 1) sp = 1;
+    const long long tiles = ntiles(best);
+    const long long units = tiles * (long long)nkt;
+    const long long pmax = 256LL * igemm_resident_blocks(best);
+    long long p;
+    *granule = 1;
+    if (nkt < 16 && tiles >= pmax) {            // short K (1x1 shortcuts): whole tiles
+        *granule = nkt;
+        p = pmax;
+    } else if (large) {
+        p = pmax;
+        if (p > units / 4) p = units / 4;
+    } else if (tiles >= 160 && tiles <= pmax) {
+        *granule = nkt;
+        p = tiles;
+    } else {
+        p = units / min_units;
+        if (p > pmax) p = pmax;
     }
-    if (sp > nkt) sp = nkt;
+    if (p < 1) p = 1;
     *tile = best;
-    *splits = sp;
+    *nblocks = (int)p;
 }
 
 struct ConvCall {
     const float* x; int N, H, W, in_pitch;
     const float* resid; int res_pitch;
     float* out; int out_pitch, out_coff, cout_store;
-    int flags; int tile; int splitk;
+    int flags; int tile; int splitk;      // splitk: ignored (stream-K balances K itself)
     float* partial; size_t partial_cap;   // floats
-    bool partial_only;                    // FC: leave the slabs for a custom finish
-    int* splits_out;
+    int* tickets; size_t tickets_cap;
 };
 
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
@@ -297,32 +310,23 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     a.res_pitch = c.res_pitch; a.border_bias = L.border; a.flags = c.flags;
     if (L.pad_mode == 1 && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "reflect pad needs H,W >= 2");
     if (L.border && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "border-class bias needs H,W >= 2");
-    int tile, splits;
-    plan_conv(M, L.cout_pad, a.nkt, c.tile, c.splitk, &tile, &splits);
-    if (splits > 1 || c.partial_only) {
-        if (L.border) splits = c.partial_only ? splits : 1;
-        while (splits > 1 && (size_t)splits * M * L.cout_pad > c.partial_cap) --splits;
-        if (c.partial_only && (size_t)splits * M * L.cout_pad > c.partial_cap)
-            return fail(h, FFR_ERR_NOMEM, "split-K workspace too small");
-    }
+    int tile, nblocks;
+    plan_conv(M, L.cout_pad, a.nkt, c.tile, &tile, &nblocks, &a.granule);
     int bm, bn;
     igemm_tile_shape(tile, &bm, &bn);
     a.mtiles = (int)((M + bm - 1) / bm);
     a.ntiles = L.cout_pad / bn;
-    a.kt_per_split = (a.nkt + splits - 1) / splits;
-    splits = (a.nkt + a.kt_per_split - 1) / a.kt_per_split;
-    a.splits = splits;
-    a.partial = (splits > 1 || c.partial_only) ? c.partial : nullptr;
-    if (c.splits_out) *c.splits_out = splits;
+    const long long units = (long long)a.mtiles * a.ntiles * a.nkt;
+    const bool cut = a.granule == 1 && ((units % nblocks) != 0 || ((units / nblocks) % a.nkt) != 0);
+    if (cut && (size_t)nblocks * 2 * bm * bn > c.partial_cap) return fail(h, FFR_ERR_NOMEM, "stream-K workspace too small");
+    a.partial = c.partial;
+    a.tickets = c.tickets;
+    if ((size_t)a.mtiles * a.ntiles > c.tickets_cap) return fail(h, FFR_ERR_NOMEM, "stream-K ticket array too small");
     const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
     const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
     {
         Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes);
-        HIPCK(h, launch_igemm(a, tile, st));
-    }
-    if (a.partial && !c.partial_only) {
-        Scope s(h, st, FFR_KC_CONV_IGEMM, 0, 0);
-        HIPCK(h, launch_splitk_reduce(a, st));
+        HIPCK(h, launch_igemm(a, tile, nblocks, st));
     }
     return FFR_OK;
 }
@@ -344,6 +348,7 @@ struct Work {
     float *bufA, *bufB, *t1, *res, *sc, *scale, *trunk_bn;
     // shared
     float* partial; size_t partial_cap;
+    int* tickets; size_t tickets_cap;
     // recnet
     float *X, *bufS, *bufF, *bufM, *s256a, *s256b, *s256c, *ms, *m512a, *m512b, *m512c, *dbg;
     size_t total;
@@ -361,7 +366,7 @@ Work layout(char* base, int N, int H, int W) {
     w.sc = a.take(S0 / 8);
     w.scale = a.take((size_t)N * 512);
     w.trunk_bn = a.take((size_t)N * hw16 * 512);
-    w.partial_cap = (size_t)32 * (N > 64 ? N : 64) * 512 + (size_t)8 * 1024 * 1024;
+    w.partial_cap = (size_t)1024 * 2 * 128 * 128 / 2 + 4096;   // 64 MiB: nblocks * 2 slabs of one tile (fp32)
     w.partial = a.take(w.partial_cap);
     const size_t P = (size_t)N * 49;
     w.X = a.take(P * 512);
@@ -389,8 +394,20 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
             return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu workspace bytes failed", need);
         h->arena = (char*)p;
         h->arena_bytes = need;
+
+    }
+    const size_t need_t = (size_t)N * H * W / 64 + 4096;
+    if (need_t > h->tickets_cap) {
+        if (h->tickets) { hipDeviceSynchronize(); hipFree(h->tickets); h->tickets = nullptr; h->tickets_cap = 0; }
+        void* p = nullptr;
+        if (hipMalloc(&p, need_t * sizeof(int)) != hipSuccess) return fail(h, FFR_ERR_NOMEM, "hipMalloc of the ticket array failed");
+        if (hipMemset(p, 0, need_t * sizeof(int)) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipMemset failed");
+        h->tickets = (int*)p;
+        h->tickets_cap = need_t;
     }
     *w = layout(h->arena, N, H, W);
+    w->tickets = h->tickets;
+    w->tickets_cap = h->tickets_cap;
     return FFR_OK;
 }
 
@@ -411,12 +428,12 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         ConvCall c1{};
         c1.x = cur; c1.N = N; c1.H = ch; c1.W = cw; c1.in_pitch = b.cin;
         c1.out = w.t1; c1.out_pitch = b.depth; c1.cout_store = b.depth;
-        c1.partial = w.partial; c1.partial_cap = w.partial_cap;
+        c1.partial = w.partial; c1.partial_cap = w.partial_cap; c1.tickets = w.tickets; c1.tickets_cap = w.tickets_cap;
         RC(run_conv(h, b.c1, c1, st));
         ConvCall c2{};
         c2.x = w.t1; c2.N = N; c2.H = ch; c2.W = cw; c2.in_pitch = b.depth;
         c2.out = w.res; c2.out_pitch = b.depth; c2.cout_store = b.depth;
-        c2.partial = w.partial; c2.partial_cap = w.partial_cap;
+        c2.partial = w.partial; c2.partial_cap = w.partial_cap; c2.tickets = w.tickets; c2.tickets_cap = w.tickets_cap;
         RC(run_conv(h, b.c2, c2, st));
         {
             const double e = (double)N * ho * wo * b.depth;
@@ -428,7 +445,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             ConvCall cs{};
             cs.x = cur; cs.N = N; cs.H = ch; cs.W = cw; cs.in_pitch = b.cin;
             cs.out = w.sc; cs.out_pitch = b.depth; cs.cout_store = b.depth;
-            cs.partial = w.partial; cs.partial_cap = w.partial_cap;
+            cs.partial = w.partial; cs.partial_cap = w.partial_cap; cs.tickets = w.tickets; cs.tickets_cap = w.tickets_cap;
             RC(run_conv(h, b.sc, cs, st));
             scp = w.sc;
         }
@@ -458,13 +475,11 @@ int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int 
         if (P != 49) return fail(h, FFR_ERR_UNSUPPORTED, "output_layer needs a 7x7 trunk map (112x112 input)");
         ConvCall c{};
         c.x = t; c.N = N; c.H = 1; c.W = 1; c.in_pitch = 25088;
-        c.out = nullptr; c.out_pitch = 512; c.cout_store = 512;
-        c.partial = w.partial; c.partial_cap = w.partial_cap; c.partial_only = true;
-        int splits = 1;
-        c.splits_out = &splits;
+        c.out = w.scale; c.out_pitch = 512; c.cout_store = 512;     // SE scale buffer is free here
+        c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
         RC(run_conv(h, h->fc, c, st));
-        Scope s(h, st, FFR_KC_HEAD, 3.0 * N * 512, 4.0 * N * 512 * (splits + 1));
-        HIPCK(h, launch_head_finish(w.partial, splits, N, 512, h->fc.bias, f, st));
+        Scope s(h, st, FFR_KC_HEAD, 3.0 * N * 512, 8.0 * N * 512);
+        HIPCK(h, launch_head_finish(w.scale, 1, N, 512, nullptr, f, st));
     }
     return FFR_OK;
 }
@@ -477,7 +492,7 @@ int conv_rec(ffr_handle* h, const Work& w, const ConvW& L, const float* x, int i
     ConvCall c{};
     c.x = x; c.N = N; c.H = 7; c.W = 7; c.in_pitch = in_pitch; c.resid = resid; c.res_pitch = res_pitch;
     c.out = out; c.out_pitch = out_pitch; c.out_coff = out_coff; c.cout_store = L.cout_pad; c.flags = flags;
-    c.partial = w.partial; c.partial_cap = w.partial_cap;
+    c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
     return run_conv(h, L, c, st);
 }
 
@@ -594,6 +609,7 @@ void ffr_destroy(ffr_handle* h) {
     free_list(h->enc_allocs);
     free_list(h->rec_allocs);
     if (h->arena) hipFree(h->arena);
+    if (h->tickets) hipFree(h->tickets);
     if (h->zero) hipFree(h->zero);
     for (auto& r : h->prof_log) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto e : h->ev_pool) hipEventDestroy(e);
@@ -883,7 +899,7 @@ int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream) {
     ConvCall c{};
     c.x = d->x; c.N = d->N; c.H = d->H; c.W = d->W; c.in_pitch = d->in_pitch; c.resid = d->resid; c.res_pitch = d->res_pitch;
     c.out = d->out; c.out_pitch = d->out_pitch; c.out_coff = d->out_coff; c.cout_store = d->cout_store; c.flags = d->flags;
-    c.tile = d->tile; c.splitk = d->splitk; c.partial = w.partial; c.partial_cap = w.partial_cap;
+    c.tile = d->tile; c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
     return run_conv(h, L, c, (hipStream_t)stream);
 }
 

@@ -17,9 +17,10 @@ struct IgemmArgs {
     const float* resid;   // [M][res_pitch] or null
     float* out;           // [M][out_pitch] (+out_coff)
     const float* zero;    // >= 128 B of zeros (source of zero-padded taps)
-    float* partial;       // split-K slabs [splits][M][cout_pad], or null
+    float* partial;       // stream-K slabs [nblocks][2][BM*BN]
+    int* tickets;         // stream-K arrival counters, one per tile, zero between launches
     int N, H, W, Ho, Wo, in_pitch, cin_pad, R, S, stride, pad, pad_mode;
-    int M, KK, nkt, kt_per_split, splits;
+    int M, KK, nkt, granule;
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch;
     int border_bias, flags;      // flags bit0: sigmoid at the end
     int mtiles, ntiles;
@@ -28,9 +29,10 @@ enum { IGEMM_TILE_128x128 = 1, IGEMM_TILE_128x64 = 2, IGEMM_TILE_64x64 = 3, IGEM
        IGEMM_NTILES = 4 };
 void igemm_tile_shape(int tile, int* bm, int* bn);
 hipError_t igemm_init();   // raises the dynamic-LDS limit of the instantiations
-hipError_t launch_igemm(const IgemmArgs& a, int tile, hipStream_t stream);
-// sums split-K slabs and applies the (non-border) epilogue of `a`
-hipError_t launch_splitk_reduce(const IgemmArgs& a, hipStream_t stream);
+int igemm_resident_blocks(int tile);
+// persistent stream-K launch over `nblocks` blocks; tiles that are cut are finished inside
+// the launch by the last contributor (a.partial / a.tickets)
+hipError_t launch_igemm(const IgemmArgs& a, int tile, int nblocks, hipStream_t stream);
 
 // ---- trunk elementwise (elementwise.hip) -------------------------------------------
 // stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded

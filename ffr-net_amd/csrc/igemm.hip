@@ -38,18 +38,34 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     constexpr int STAGE_FLOATS = (BM + BN) * 32;
     static_assert(WARPS_M * WARPS_N == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* s_cls = reinterpret_cast<int*>(smem + 2 * STAGE_FLOATS);
+    constexpr int MAIN_FLOATS = (2 * STAGE_FLOATS > BM * (BN + 4)) ? 2 * STAGE_FLOATS : BM * (BN + 4);
+    int* s_cls = reinterpret_cast<int*>(smem + MAIN_FLOATS);
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
-
-    const int bid = blockIdx.x;
-    const int nt = bid % a.ntiles, mt = bid / a.ntiles;
-    const int split = blockIdx.y;
-    const int m0 = mt * BM, n0 = nt * BN;
     const int HoWo = a.Ho * a.Wo;
+
+    // ---- stream-K: this persistent block owns the contiguous range [u, uend) of the
+    // launch's (tile, K-tile) units; every block gets the same amount of MFMA work,
+    // whatever the tile count is modulo the 256 CUs ----------------------------------------
+    const long long U = (long long)a.mtiles * a.ntiles * a.nkt;
+    const long long G = U / a.granule;      // granule = 1, or nkt when tiles are not cut (tiny K)
+    long long u = (long long)blockIdx.x * G / gridDim.x * a.granule;
+    const long long uend = (long long)(blockIdx.x + 1) * G / gridDim.x * a.granule;
+    while (u < uend) {
+    const int tile_id = (int)(u / a.nkt);
+    const int kb = (int)(u - (long long)tile_id * a.nkt);
+    const int nk = (uend - u < (long long)(a.nkt - kb)) ? (int)(uend - u) : a.nkt - kb;
+    u += nk;
+    const int nt = tile_id % a.ntiles, mt = tile_id / a.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    __syncthreads();        // LDS (stages, s_cls) of the previous segment is free
+    // the thread id is re-read through an opaque asm every segment: otherwise hipcc hoists every
+    // lane-dependent address of the epilogue out of the segment loop and keeps ~100 extra
+    // VGPRs alive across the MFMA loop (128x64: 196 instead of ~100 registers -> 2 blocks/CU)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
 
     // ---- per-thread staging rows -------------------------------------------------
     const int srow = tid >> 3;                              // 0..31
@@ -79,11 +95,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         s_cls[tid] = rc * 3 + cc;
     }
 
-    // ---- K range of this block (split-K) and its tap state ---------------------------
-    const int kt_begin = split * a.kt_per_split;
-    int nk = a.nkt - kt_begin;
-    if (nk > a.kt_per_split) nk = a.kt_per_split;
-    const int kbase0 = kt_begin * 32;
+    // ---- tap state at the first K-tile of this segment -----------------------------------
+    const int kbase0 = kb * 32;
     int tap = kbase0 / a.cin_pad;
     int c0 = kbase0 - tap * a.cin_pad;
     int tr = tap / a.S, ts = tap - tr * a.S;
@@ -210,71 +223,107 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     tile_body.template operator()<true>((nk - 1) & 1);
 #undef FFR_PIN
 
-    // ---- epilogue ----------------------------------------------------------------
-    const int ncol0 = n0 + wn * WN + frow;
-    if (a.partial) {
-        float* dst = a.partial + (size_t)split * a.M * a.cout_pad;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m < a.M) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) dst[(size_t)m * a.cout_pad + ncol0 + j * 32] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    float slope[TN], bias0[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        slope[j] = a.slope ? a.slope[ncol0 + j * 32] : 1.0f;
-        bias0[j] = a.bias[ncol0 + j * 32];
-    }
+    // ---- epilogue: accumulators -> LDS (C tile, row stride BN+4) -> whole rows, 16 B per lane ----
+    // (register-layout stores are 128-B pieces, one instruction per accumulator register: 64
+    //  store instructions per wave for a 64x64 wave tile took as long as 10-20 K-tiles)
+    constexpr int LDC = BN + 4;
+    constexpr int NQ4 = BN / 4;            // float4 columns per row
+    constexpr int RPP = 256 / NQ4;         // rows per pass of the 256 threads
+    float* sC = smem;
+    __syncthreads();                       // every wave is done reading the stage buffers
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const int m = m0 + ml;
-            if (m < a.M) {
-                const int cls = a.border_bias ? s_cls[ml] : 0;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = ncol0 + j * 32;
-                    float v = acc[i][j][r] + (a.border_bias ? a.bias[cls * a.cout_pad + n] : bias0[j]);
-                    v = v >= 0.f ? v : v * slope[j];
-                    if (a.resid) v += a.resid[(size_t)m * a.res_pitch + n];
-                    if (a.flags & 1) v = 1.0f / (1.0f + __expf(-v));
-                    if (n < a.cout_store) a.out[(size_t)m * a.out_pitch + a.out_coff + n] = v;
+            for (int j = 0; j < TN; ++j) sC[ml * LDC + wn * WN + j * 32 + frow] = acc[i][j][r];
+        }
+    __syncthreads();
+    const int erow = tid / NQ4, ecol = (tid - erow * NQ4) * 4;
+    bool finish = true;                    // this block applies the epilogue and stores the tile
+    if (nk != a.nkt) {
+        // Partial K range (stream-K cut).  Every contributor stores its raw sums to its slab
+        // (slot 0: segment does not start at k = 0, slot 1: it does), publishes it with an
+        // agent-scope release and draws a ticket; the block that draws the last ticket adds
+        // the slabs in block order (bitwise reproducible) and finishes the tile.  Nobody waits.
+        const long long tb = (long long)tile_id * a.nkt;
+        const int P = gridDim.x;
+        const int b_lo = (int)(((tb + 1) * P - 1) / G), b_hi = (int)(((tb + a.nkt) * P - 1) / G);
+        float* dst = a.partial + ((size_t)blockIdx.x * 2 + (kb != 0 ? 0 : 1)) * (BM * BN);
+#pragma unroll 4
+        for (int p = 0; p < BM / RPP; ++p) {
+            const int ml = p * RPP + erow;
+            *reinterpret_cast<f32x4*>(dst + ml * BN + ecol) = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == b_hi - b_lo) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            s_cls[BM] = old;
+        }
+        __syncthreads();
+        finish = s_cls[BM] == b_hi - b_lo;
+        if (finish) {
+#pragma unroll 2
+            for (int p = 0; p < BM / RPP; ++p) {
+                const int ml = p * RPP + erow;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                for (int bb = b_lo; bb <= b_hi; ++bb) {
+                    if (bb == (int)blockIdx.x) {
+                        sum += *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+                    } else {
+                        const int slot = ((long long)bb * G / P * a.granule > tb) ? 0 : 1;
+                        sum += *reinterpret_cast<const f32x4*>(a.partial + ((size_t)bb * 2 + slot) * (BM * BN) + ml * BN + ecol);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(sC + ml * LDC + ecol) = sum;   // same thread re-reads it below
+            }
+        }
+    }
+    if (finish) {
+        const int n = n0 + ecol;
+        const bool vec = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0 && n + 4 <= a.cout_store;
+        f32x4 slope4 = {1.f, 1.f, 1.f, 1.f};
+        if (a.slope) slope4 = *reinterpret_cast<const f32x4*>(a.slope + n);
+        const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll 4
+        for (int p = 0; p < BM / RPP; ++p) {
+            const int ml = p * RPP + erow;
+            const int m = m0 + ml;
+            if (m >= a.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+            v += a.border_bias ? *reinterpret_cast<const f32x4*>(a.bias + s_cls[ml] * a.cout_pad + n) : bias0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
+            if (vec) {
+                if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)m * a.res_pitch + n);
+                if (a.flags & 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+                }
+                *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.out_pitch + a.out_coff + n) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < a.cout_store) {
+                        float x = v[e];
+                        if (a.resid) x += a.resid[(size_t)m * a.res_pitch + n + e];
+                        if (a.flags & 1) x = 1.0f / (1.0f + __expf(-x));
+                        a.out[(size_t)m * a.out_pitch + a.out_coff + n + e] = x;
+                    }
                 }
             }
         }
-}
-
-// ---- split-K reduction + epilogue ------------------------------------------------------
-__global__ __launch_bounds__(256) void k_splitk_reduce(const IgemmArgs a) {
-    const int nq = a.cout_pad >> 2;
-    const size_t total = (size_t)a.M * nq;
-    const size_t slab = (size_t)a.M * a.cout_pad;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int m = (int)(idx / nq);
-        const int n = (int)(idx - (size_t)m * nq) * 4;
-        f32x4 s = *reinterpret_cast<const f32x4*>(a.partial + (size_t)m * a.cout_pad + n);
-        for (int k = 1; k < a.splits; ++k) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(a.partial + k * slab + (size_t)m * a.cout_pad + n);
-            s += p;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = s[e] + a.bias[n + e];
-            if (a.slope) v = v >= 0.f ? v : v * a.slope[n + e];
-            if (a.resid) v += a.resid[(size_t)m * a.res_pitch + n + e];
-            if (a.flags & 1) v = 1.0f / (1.0f + __expf(-v));
-            if (n + e < a.cout_store) a.out[(size_t)m * a.out_pitch + a.out_coff + n + e] = v;
-        }
     }
+    }   // stream-K segment loop
 }
 
 void igemm_tile_shape(int tile, int* bm, int* bn) {
@@ -287,7 +336,10 @@ void igemm_tile_shape(int tile, int* bm, int* bn) {
     }
 }
 
-static size_t igemm_lds_bytes(int bm, int bn) { return (size_t)2 * (bm + bn) * 32 * 4 + (size_t)bm * 4; }
+static size_t igemm_lds_bytes(int bm, int bn) {
+    size_t stages = (size_t)2 * (bm + bn) * 32, ctile = (size_t)bm * (bn + 4);
+    return (stages > ctile ? stages : ctile) * 4 + (size_t)bm * 4 + 16;
+}
 
 hipError_t igemm_init() {
     hipError_t e;
@@ -306,11 +358,21 @@ hipError_t igemm_init() {
     return e;
 }
 
-hipError_t launch_igemm(const IgemmArgs& a, int tile, hipStream_t stream) {
+int igemm_resident_blocks(int tile) {   // blocks of 256 threads one CU holds (LDS-limited)
+    switch (tile) {
+        case IGEMM_TILE_128x128: return 2;
+        case IGEMM_TILE_128x64: return 3;
+        case IGEMM_TILE_64x64: return 4;
+        case IGEMM_TILE_256x64: return 1;
+        default: return 0;
+    }
+}
+
+hipError_t launch_igemm(const IgemmArgs& a, int tile, int nblocks, hipStream_t stream) {
     int bm, bn;
     igemm_tile_shape(tile, &bm, &bn);
-    if (!bm) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.splits, 1);
+    if (!bm || nblocks <= 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblocks, 1, 1);
     const size_t lds = igemm_lds_bytes(bm, bn);
 #define FFR_LAUNCH(BM, BN, WMM, WNN)                                                                      \
     if (a.pad_mode == 1) hipLaunchKernelGGL((k_igemm<BM, BN, WMM, WNN, 1>), grid, dim3(256), lds, stream, a); \
@@ -322,14 +384,6 @@ hipError_t launch_igemm(const IgemmArgs& a, int tile, hipStream_t stream) {
         case IGEMM_TILE_256x64: FFR_LAUNCH(256, 64, 4, 1) break;
     }
 #undef FFR_LAUNCH
-    return hipGetLastError();
-}
-
-hipError_t launch_splitk_reduce(const IgemmArgs& a, hipStream_t stream) {
-    const size_t total = (size_t)a.M * (a.cout_pad >> 2);
-    unsigned blocks = (unsigned)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
