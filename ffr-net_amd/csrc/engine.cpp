@@ -324,7 +324,34 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     if ((size_t)a.mtiles * a.ntiles > c.tickets_cap) return fail(h, FFR_ERR_NOMEM, "stream-K ticket array too small");
     const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
     const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
-    {
+    static const bool trace_on = getenv("FFR_IGEMM_TRACE") != nullptr;
+    if (trace_on) {   // diagnostic: per-block clock sums, printed after a stream sync
+        unsigned long long* dbuf = nullptr;
+        HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nblocks * 8 * sizeof(unsigned long long)));
+        a.trace = dbuf;
+        HIPCK(h, launch_igemm(a, tile, nblocks, st));
+        HIPCK(h, hipStreamSynchronize(st));
+        std::vector<unsigned long long> t((size_t)nblocks * 8);
+        HIPCK(h, hipMemcpy(t.data(), dbuf, t.size() * 8, hipMemcpyDeviceToHost));
+        HIPCK(h, hipFree(dbuf));
+        a.trace = nullptr;
+        double acc[4] = {0, 0, 0, 0}, segs = 0, e1 = 0, e2 = 0, ghz = 0;
+        unsigned long long r0 = ~0ull, r1 = 0, smax = 0;
+        for (int b = 0; b < nblocks; ++b) {
+            const unsigned long long* q = &t[(size_t)b * 8];
+            for (int k = 0; k < 4; ++k) acc[k] += (double)q[k];
+            segs += (double)q[4];
+            ghz += (double)(q[0] + q[1] + q[2] + q[3]) / ((double)(q[6] - q[5]) * 10.0);
+            e1 += (double)(q[7] >> 32); e2 += (double)(q[7] & 0xffffffffull);
+            if (q[5] < r0) r0 = q[5];
+            if (q[5] > smax) smax = q[5];
+            if (q[6] > r1) r1 = q[6];
+        }
+        fprintf(stderr, "[igemm trace] tile %d blocks %d units %lld nkt %d segs/blk %.2f | per segment: setup %.0f prologue %.0f "
+                        "loop %.0f (%.0f per K-tile) epilogue %.0f (first barrier at %.0f, C in LDS at %.0f) cyc | span %.1f us, starts within %.1f us, shader clock %.2f GHz\n",
+                tile, nblocks, units, a.nkt, segs / nblocks, acc[0] / segs, acc[1] / segs, acc[2] / segs,
+                acc[2] / ((double)units), acc[3] / segs, e1 / segs, e2 / segs, (double)(r1 - r0) / 100.0, (double)(smax - r0) / 100.0, ghz / nblocks);
+    } else {
         Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes);
         HIPCK(h, launch_igemm(a, tile, nblocks, st));
     }

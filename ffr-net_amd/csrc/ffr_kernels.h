@@ -19,6 +19,7 @@ struct IgemmArgs {
     const float* zero;    // >= 128 B of zeros (source of zero-padded taps)
     float* partial;       // stream-K slabs [nblocks][2][BM*BN]
     int* tickets;         // stream-K arrival counters, one per tile, zero between launches
+    unsigned long long* trace;   // diagnostic (FFR_IGEMM_TRACE): 8 words per block, or null
     int N, H, W, Ho, Wo, in_pitch, cin_pad, R, S, stride, pad, pad_mode;
     int M, KK, nkt, granule;
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch;

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     static_assert(WARPS_M * WARPS_N == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MAIN_FLOATS = (2 * STAGE_FLOATS > BM * (BN + 4)) ? 2 * STAGE_FLOATS : BM * (BN + 4);
-    int* s_cls = reinterpret_cast<int*>(smem + MAIN_FLOATS);
+    int* s_cls = reinterpret_cast<int*>(smem + MAIN_FLOATS);     // [BM] border class per row, [BM] = ticket
+    float* s_bias = smem + MAIN_FLOATS + BM + 4;                // [9][BN] border-class biases of this tile
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WARPS_N, wn = wave % WARPS_N;
@@ -52,6 +53,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     const long long G = U / a.granule;      // granule = 1, or nkt when tiles are not cut (tiny K)
     long long u = (long long)blockIdx.x * G / gridDim.x * a.granule;
     const long long uend = (long long)(blockIdx.x + 1) * G / gridDim.x * a.granule;
+    unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_seg = 0, tr_t = 0, tr_rt0 = 0;   // FFR_IGEMM_TRACE only
+    if (a.trace) tr_rt0 = __builtin_amdgcn_s_memrealtime();
     while (u < uend) {
     const int tile_id = (int)(u / a.nkt);
     const int kb = (int)(u - (long long)tile_id * a.nkt);
@@ -65,6 +68,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     // VGPRs alive across the MFMA loop (128x64: 196 instead of ~100 registers -> 2 blocks/CU)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
+    if (a.trace) { tr_t = __builtin_amdgcn_s_memtime(); ++tr_seg; }
     const int lane = tid & 63;
 
     // ---- per-thread staging rows -------------------------------------------------
@@ -93,6 +97,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         const int rc = (h0 < 0) ? 0 : ((h0 + a.R - 1 >= a.H) ? 2 : 1);
         const int cc = (w0 < 0) ? 0 : ((w0 + a.S - 1 >= a.W) ? 2 : 1);
         s_cls[tid] = rc * 3 + cc;
+    }
+    if (a.border_bias) {
+        for (int idx = tid; idx < 9 * BN; idx += 256) s_bias[idx] = a.bias[(idx / BN) * a.cout_pad + n0 + (idx % BN)];
     }
 
     // ---- tap state at the first K-tile of this segment -----------------------------------
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         }
     };
 
+    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[0] += t - tr_t; tr_t = t; }
     // prologue: tile 0 -> stage 0, its first fragments -> slot 0
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma_piece(0, d);
@@ -219,8 +227,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) read_piece(0, smem, pc[0], r);
     FFR_PIN;
+    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[1] += t - tr_t; tr_t = t; }
     for (int it = 0; it + 1 < nk; ++it) tile_body.template operator()<false>(it & 1);
     tile_body.template operator()<true>((nk - 1) & 1);
+    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[2] += t - tr_t; tr_t = t; }
 #undef FFR_PIN
 
     // ---- epilogue: accumulators -> LDS (C tile, row stride BN+4) -> whole rows, 16 B per lane ----
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     constexpr int RPP = 256 / NQ4;         // rows per pass of the 256 threads
     float* sC = smem;
     __syncthreads();                       // every wave is done reading the stage buffers
+    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[4] += t - tr_t; }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
             for (int j = 0; j < TN; ++j) sC[ml * LDC + wn * WN + j * 32 + frow] = acc[i][j][r];
         }
     __syncthreads();
+    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[5] += t - tr_t; }
     const int erow = tid / NQ4, ecol = (tid - erow * NQ4) * 4;
     bool finish = true;                    // this block applies the epilogue and stores the tile
     if (nk != a.nkt) {
@@ -294,27 +306,68 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         f32x4 slope4 = {1.f, 1.f, 1.f, 1.f};
         if (a.slope) slope4 = *reinterpret_cast<const f32x4*>(a.slope + n);
         const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.bias + n);
-#pragma unroll 4
-        for (int p = 0; p < BM / RPP; ++p) {
-            const int ml = p * RPP + erow;
-            const int m = m0 + ml;
-            if (m >= a.M) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
-            v += a.border_bias ? *reinterpret_cast<const f32x4*>(a.bias + s_cls[ml] * a.cout_pad + n) : bias0;
+        // No global LOAD may sit between the stores of this loop: vmcnt retires in order, so the
+        // wait in front of a load's first use also drains every older store (a full HBM write
+        // latency per pass: 37k of the 42k epilogue cycles measured).  Border-class biases come
+        // from LDS; residual rows are fetched one batch AHEAD of the batch being stored.
+        constexpr int NP = BM / RPP;
+        constexpr int BATCH = NP < 4 ? NP : 4;
+        auto finish_tile = [&]<bool BORDER, bool RESID>() {
+            f32x4 rs[BATCH], rn[BATCH];
+            auto load_resid = [&](f32x4* dstv, int p0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
-            if (vec) {
-                if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + (size_t)m * a.res_pitch + n);
-                if (a.flags & 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+                for (int k = 0; k < BATCH; ++k) {
+                    const int m = m0 + (p0 + k) * RPP + erow;
+                    dstv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (m < a.M) dstv[k] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)m * a.res_pitch + n);
                 }
-                *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.out_pitch + a.out_coff + n) = v;
+            };
+            if (RESID) load_resid(rs, 0);
+#pragma unroll
+            for (int p0 = 0; p0 < NP; p0 += BATCH) {
+                if (RESID && p0 + BATCH < NP) load_resid(rn, p0 + BATCH);
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {
+                    const int ml = (p0 + k) * RPP + erow;
+                    const int m = m0 + ml;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+                    if (BORDER) v += *reinterpret_cast<const f32x4*>(s_bias + s_cls[ml] * BN + ecol);
+                    else v += bias0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
+                    if (RESID) v += rs[k];
+                    if (a.flags & 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+                    }
+                    if (m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.out_pitch + a.out_coff + n) = v;
+                }
+                if (RESID) {
+#pragma unroll
+                    for (int k = 0; k < BATCH; ++k) rs[k] = rn[k];
+                }
+            }
+        };
+        if (vec) {
+            if (a.border_bias) {
+                if (a.resid) finish_tile.template operator()<true, true>();
+                else finish_tile.template operator()<true, false>();
             } else {
+                if (a.resid) finish_tile.template operator()<false, true>();
+                else finish_tile.template operator()<false, false>();
+            }
+        } else {
+            // generic slow path: channel slices that are not 16-B aligned / ragged cout
+            for (int p = 0; p < NP; ++p) {
+                const int ml = p * RPP + erow;
+                const int m = m0 + ml;
+                if (m >= a.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+                v += a.border_bias ? *reinterpret_cast<const f32x4*>(s_bias + s_cls[ml] * BN + ecol) : bias0;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (n + e < a.cout_store) {
-                        float x = v[e];
+                        float x = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
                         if (a.resid) x += a.resid[(size_t)m * a.res_pitch + n + e];
                         if (a.flags & 1) x = 1.0f / (1.0f + __expf(-x));
                         a.out[(size_t)m * a.out_pitch + a.out_coff + n + e] = x;
@@ -323,7 +376,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
             }
         }
     }
+    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[3] += t - tr_t; tr_t = t; }
     }   // stream-K segment loop
+    if (a.trace && threadIdx.x == 0) {
+        unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
+        t[0] = tr_acc[0]; t[1] = tr_acc[1]; t[2] = tr_acc[2]; t[3] = tr_acc[3]; t[4] = tr_seg;
+        t[5] = tr_rt0; t[6] = __builtin_amdgcn_s_memrealtime(); t[7] = (tr_acc[4] << 32) | (tr_acc[5] & 0xffffffffull);
+    }
 }
 
 void igemm_tile_shape(int tile, int* bm, int* bn) {
@@ -338,7 +397,7 @@ void igemm_tile_shape(int tile, int* bm, int* bn) {
 
 static size_t igemm_lds_bytes(int bm, int bn) {
     size_t stages = (size_t)2 * (bm + bn) * 32, ctile = (size_t)bm * (bn + 4);
-    return (stages > ctile ? stages : ctile) * 4 + (size_t)bm * 4 + 16;
+    return (stages > ctile ? stages : ctile) * 4 + (size_t)(bm + 4) * 4 + (size_t)9 * bn * 4;
 }
 
 hipError_t igemm_init() {
