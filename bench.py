@@ -40,12 +40,26 @@ def state_dict_specs():
             {k: tuple(v.shape) for k, v in rec.state_dict().items()})
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants 16: 256 torch threads there ran the
+    oracle 100x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(sd_e, sd_r, budget_s=12.0):
     """Oracle (kind 'port') on the host cores: batches of 8 images (BASELINE configs[0])
     until ~budget_s of CPU work, after one warm-up batch."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import ffr_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     x = synth.synth_images(8, seed=123)
     O.embed(sd_e, sd_r, x)
@@ -58,8 +72,9 @@ def cpu_baseline(sd_e, sd_r, budget_s=12.0):
             break
     return {'value': round(n / dt, 2), 'unit': 'embeddings/s', 'cores': torch.get_num_threads(),
             'kind': 'port',
-            'sample': '%d images in batches of 8 (configs[0] shape), %.1f s, torch %s CPU, %d threads'
-                      % (n, dt, torch.__version__, torch.get_num_threads())}
+            'sample': '%d images in batches of 8 (configs[0] shape), %.1f s, torch %s CPU, %d threads '
+                      '(%d logical CPUs visible)' % (n, dt, torch.__version__, torch.get_num_threads(),
+                                                     os.cpu_count() or 0)}
 
 
 def main():
