@@ -89,30 +89,51 @@ hipError_t launch_stem(const float* x, const float* w, const float* bias, const 
 }
 
 // ---------------------------------------------------------------------------------------
-// SEModule (pretrain/model_ir_se50.py:29-36), one block per image:
-//   mean over HW -> fc1 (C -> C/16) -> ReLU -> fc2 (C/16 -> C) -> sigmoid -> scale[n][c]
+// SEModule (pretrain/model_ir_se50.py:29-36) in two launches:
+//   k_se_pool: grid (N, S) -- block (n, s) sums its slice of the HW rows of image n into
+//              part[n][s][C] (one image per block left the HBM pipe at 2 TB/s: 256 blocks
+//              of 256 threads cannot keep enough loads in flight);
+//   k_se_fc:   per image: mean -> fc1 (C -> C/16) -> ReLU -> fc2 -> sigmoid -> scale[n][c].
+// Fixed summation order (rows inside a slice, then slices): bitwise reproducible.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_se(const float* __restrict__ res, int HW, int C,
-                                           const float* __restrict__ fc1, const float* __restrict__ fc2,
-                                           float* __restrict__ scale) {
+__global__ __launch_bounds__(256) void k_se_pool(const float* __restrict__ res, int HW, int C, int S,
+                                                float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float s_part[1024];   // rows_par x C = 1024 for every C in {64..512}
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x, sl = blockIdx.y;
+    const int cq = C >> 2;                 // float4 lanes per row: 16..128
+    const int rows_par = 256 / cq;         // rows processed in parallel: 16..2
+    const int lane_c = tid % cq, rgrp = tid / cq;
+    const int r0 = (int)((long long)sl * HW / S), r1 = (int)((long long)(sl + 1) * HW / S);
+    const float* base = res + (size_t)n * HW * C;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int r = r0 + rgrp;
+    for (; r + rows_par < r1; r += 2 * rows_par) {
+        acc0 += *reinterpret_cast<const f32x4*>(base + (size_t)r * C + lane_c * 4);
+        acc1 += *reinterpret_cast<const f32x4*>(base + (size_t)(r + rows_par) * C + lane_c * 4);
+    }
+    if (r < r1) acc0 += *reinterpret_cast<const f32x4*>(base + (size_t)r * C + lane_c * 4);
+    acc0 += acc1;
+    *reinterpret_cast<f32x4*>(s_part + rgrp * C + lane_c * 4) = acc0;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int g = 0; g < rows_par; ++g) s += s_part[g * C + c];
+        part[((size_t)n * S + sl) * C + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ part, int S, int HW, int C,
+                                              const float* __restrict__ fc1, const float* __restrict__ fc2,
+                                              float* __restrict__ scale) {
     __shared__ float s_mean[512];
     __shared__ float s_hid[32];
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
-    const int cq = C >> 2;                 // float4 lanes per row: 16..128
-    const int rows_par = 256 / cq;         // rows processed in parallel: 16..2
-    const int lane_c = tid % cq, rgrp = tid / cq;
-    const float* base = res + (size_t)n * HW * C;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = rgrp; r < HW; r += rows_par)
-        acc += *reinterpret_cast<const f32x4*>(base + (size_t)r * C + lane_c * 4);
-    *reinterpret_cast<f32x4*>(s_part + rgrp * C + lane_c * 4) = acc;
-    __syncthreads();
     const float inv = 1.0f / (float)HW;
     for (int c = tid; c < C; c += 256) {
         float s = 0.f;
-        for (int g = 0; g < rows_par; ++g) s += s_part[g * C + c];
+        for (int g = 0; g < S; ++g) s += part[((size_t)n * S + g) * C + c];
         s_mean[c] = s * inv;
     }
     __syncthreads();
@@ -132,10 +153,20 @@ __global__ __launch_bounds__(256) void k_se(const float* __restrict__ res, int H
     }
 }
 
+int se_slices(int N, int HW) {
+    int S = 2048 / (N > 0 ? N : 1);
+    if (S > HW / 16) S = HW / 16;
+    if (S > 32) S = 32;
+    if (S < 1) S = 1;
+    return S;
+}
+
 hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, const float* fc2, float* scale,
-                     hipStream_t stream) {
+                     float* part, hipStream_t stream) {
     if (C > 512 || (C & 63)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_se, dim3(N), dim3(256), 0, stream, res, HW, C, fc1, fc2, scale);
+    const int S = se_slices(N, HW);
+    hipLaunchKernelGGL(k_se_pool, dim3(N, S), dim3(256), 0, stream, res, HW, C, S, part);
+    hipLaunchKernelGGL(k_se_fc, dim3(N), dim3(256), 0, stream, part, S, HW, C, fc1, fc2, scale);
     return hipGetLastError();
 }
 

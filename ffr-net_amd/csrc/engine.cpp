@@ -372,7 +372,7 @@ struct Arena {
 
 struct Work {
     // encoder
-    float *bufA, *bufB, *t1, *res, *sc, *scale, *trunk_bn;
+    float *bufA, *bufB, *t1, *res, *sc, *scale, *se_part, *trunk_bn;
     // shared
     float* partial; size_t partial_cap;
     int* tickets; size_t tickets_cap;
@@ -392,6 +392,7 @@ Work layout(char* base, int N, int H, int W) {
     w.res = a.take(S0 / 4);
     w.sc = a.take(S0 / 8);
     w.scale = a.take((size_t)N * 512);
+    w.se_part = a.take((size_t)N * 32 * 512);
     w.trunk_bn = a.take((size_t)N * hw16 * 512);
     w.partial_cap = (size_t)1024 * 2 * 128 * 128 / 2 + 4096;   // 64 MiB: nblocks * 2 slabs of one tile (fp32)
     w.partial = a.take(w.partial_cap);
@@ -465,7 +466,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_SE, e + 4.0 * N * b.depth * (b.depth / 16), 4.0 * e);
-            HIPCK(h, launch_se(w.res, N, ho * wo, b.depth, b.fc1, b.fc2, w.scale, st));
+            HIPCK(h, launch_se(w.res, N, ho * wo, b.depth, b.fc1, b.fc2, w.scale, w.se_part, st));
         }
         const float* scp = nullptr;
         if (b.has_sc) {

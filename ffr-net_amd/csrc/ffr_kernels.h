@@ -40,8 +40,10 @@ hipError_t launch_igemm(const IgemmArgs& a, int tile, int nblocks, hipStream_t s
 hipError_t launch_stem(const float* x_nchw, const float* w27x64, const float* bias, const float* slope,
                        float* out, int N, int H, int W, hipStream_t stream);
 // SE: scale[n][c] = sigmoid(fc2(relu(fc1(mean_hw res[n]))))   fc1 [C/16][C], fc2 [C][C/16]
+// part: scratch [N][se_slices(N,HW)][C] floats (<= N*32*512)
+int se_slices(int N, int HW);
 hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, const float* fc2,
-                     float* scale, hipStream_t stream);
+                     float* scale, float* part, hipStream_t stream);
 // out[n,ho,wo,c] = res*scale[n,c] + (sc ? sc[n,ho,wo,c] : x[n,ho*stride,wo*stride,c])
 hipError_t launch_combine(const float* res, const float* scale, const float* sc, const float* x,
                           float* out, int N, int Ho, int Wo, int C, int stride, hipStream_t stream);

@@ -59,8 +59,9 @@ const char* ffr_version(void);
  * pretrain/model_ir_se50.py:151-153 and models/trainer.py:98-113,201-214.
  * Eval-mode BatchNorm is folded, weights are re-packed [Cout][R][S][Cin] for the
  * NHWC implicit-GEMM kernels and uploaded; the caller keeps ownership of `t`.
- * Encoder = IR-SE50 (Backbone(50, drop, 'ir_se')): 302 fp32 entries.
- * RecNet  = RecNet(512, 7, 'bn', 'prelu'): 106 fp32 entries; "classifier.weight"
+ * Encoder = IR-SE50 (Backbone(50, drop, 'ir_se')): 347 fp32 entries (402 with the
+ * integer num_batches_tracked counters, which are not passed).
+ * RecNet  = RecNet(512, 7, 'bn', 'prelu'): 106 fp32 entries (121 in all); "classifier.weight"
  * (training-only head, models/recnet.py:396) is ignored if present.               */
 int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n);
 int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n);
@@ -134,7 +135,8 @@ int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out /* [FFR_KC_COUNT] */);
  *   resid  [N,Ho,Wo,res_pitch] added after the activation, or NULL
  *   out    [N,Ho,Wo,out_pitch], channels [out_coff, out_coff+cout_store) written
  *   pad_mode 0 = zero, 1 = reflect;  flags bit0 = sigmoid at the end
- *   tile   0 = heuristic, else 1..4 = forced tile config;  splitk 0 = heuristic      */
+ *   tile   0 = heuristic, else 1..4 = forced tile config (128x128, 128x64, 64x64, 256x64);
+ *   splitk is ignored (the kernel is stream-K: K is balanced over the blocks by itself) */
 typedef struct {
     const float* x; int N, H, W, in_pitch, cin_pad;
     const float* w; const float* bias; const float* slope;
