@@ -32,6 +32,7 @@ struct ConvW {
     float* w = nullptr;
     float* bias = nullptr;
     float* slope = nullptr;
+    float* wu = nullptr;     // Winograd F(4,3) weights [36][cout_pad][cin_pad] (G g G^T, BN folded) or null
 };
 
 struct Block {
@@ -217,6 +218,30 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     }
     RC(upload(h, owner, wp, &L->w));
     RC(upload(h, owner, bias, &L->bias));
+    L->wu = nullptr;
+    static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 256;
+    if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
+        // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
+        static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                       {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+        std::vector<float> wu((size_t)36 * L->cout_pad * L->cin_pad, 0.f);
+        for (int co = 0; co < cout; ++co) {
+            const double g = out_bn ? out_bn->s[co] : 1.0;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float* gk = W + ((size_t)co * cin + ci) * 9;
+                const double sc = (in_bn ? in_bn->s[ci] : 1.0) * g;
+                double tmp[6][3];
+                for (int i = 0; i < 6; ++i)
+                    for (int c = 0; c < 3; ++c) tmp[i][c] = G[i][0] * gk[0 * 3 + c] + G[i][1] * gk[1 * 3 + c] + G[i][2] * gk[2 * 3 + c];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        const double u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                        wu[((size_t)(i * 6 + j) * L->cout_pad + co) * L->cin_pad + ci] = (float)(u * sc);
+                    }
+            }
+        }
+        RC(upload(h, owner, wu, &L->wu));
+    }
     L->slope = nullptr;
     if (slope) {
         std::vector<float> sl(L->cout_pad, 0.f);
@@ -251,16 +276,16 @@ void block_table(int cin[24], int depth[24], int stride[24]) {
 //    efficiency measured on the MI355X: 128x128 > 128x64 > 64x64, profiles/r01_conv_sweep*);
 //  * small problems: 64x64 tiles; whole tiles per block when they fill 160..1024 blocks
 //    (nothing is cut), else stream-K with at least `min_units` K-tiles per block.
-void plan_conv(long long M, int cout_pad, int nkt, int force_tile, int* tile, int* nblocks, int* granule) {
+void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, int* tile, int* nblocks, int* granule) {
     static const int min_units = getenv("FFR_SK_MINUNITS") ? atoi(getenv("FFR_SK_MINUNITS")) : 18;
     auto ntiles = [&](int t) {
         int bm, bn;
         igemm_tile_shape(t, &bm, &bn);
-        return ((M + bm - 1) / bm) * (long long)(cout_pad / bn);
+        return ((M + bm - 1) / bm) * (long long)(cout_pad / bn) * nbatch;
     };
     int best = (cout_pad % 128 == 0) ? IGEMM_TILE_128x128 : IGEMM_TILE_128x64;
     const long long big_units = ntiles(best) * nkt;
-    const bool large = big_units / (256LL * igemm_resident_blocks(best)) >= (nkt + 3) / 4 && M >= 1024;
+    const bool large = big_units / (256LL * igemm_resident_blocks(best)) >= (nkt + 3) / 4 && M * nbatch >= 1024;
     if (!large) best = IGEMM_TILE_64x64;
     if (force_tile >= 1 && force_tile <= IGEMM_NTILES) best = force_tile;
     const long long tiles = ntiles(best);
@@ -268,7 +293,7 @@ void plan_conv(long long M, int cout_pad, int nkt, int force_tile, int* tile, in
     const long long pmax = 256LL * igemm_resident_blocks(best);
     long long p;
     *granule = 1;
-    if (nkt < 16 && tiles >= pmax) {            // short K (1x1 shortcuts): whole tiles
+    if (nkt < 16 && tiles >= pmax * 8) {        // short K and many tiles per block: whole tiles
         *granule = nkt;
         p = pmax;
     } else if (large) {
@@ -293,37 +318,23 @@ struct ConvCall {
     int flags; int tile; int splitk;      // splitk: ignored (stream-K balances K itself)
     float* partial; size_t partial_cap;   // floats
     int* tickets; size_t tickets_cap;
+    float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
 };
 
-int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
-    IgemmArgs a{};
-    a.x = c.x; a.w = L.w; a.bias = L.bias; a.slope = L.slope; a.resid = c.resid; a.out = c.out; a.zero = h->zero;
-    a.N = c.N; a.H = c.H; a.W = c.W;
-    a.Ho = (c.H + 2 * L.pad - L.R) / L.stride + 1;
-    a.Wo = (c.W + 2 * L.pad - L.S) / L.stride + 1;
-    a.in_pitch = c.in_pitch; a.cin_pad = L.cin_pad; a.R = L.R; a.S = L.S; a.stride = L.stride; a.pad = L.pad;
-    a.pad_mode = L.pad_mode;
-    const long long M = (long long)c.N * a.Ho * a.Wo;
-    if (M <= 0 || M > 0x7fffffffLL) return fail(h, FFR_ERR_ARG, "conv: bad M");
-    a.M = (int)M; a.KK = L.R * L.S * L.cin_pad; a.nkt = a.KK / 32;
-    a.cout_pad = L.cout_pad; a.cout_store = c.cout_store; a.out_pitch = c.out_pitch; a.out_coff = c.out_coff;
-    a.res_pitch = c.res_pitch; a.border_bias = L.border; a.flags = c.flags;
-    if (L.pad_mode == 1 && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "reflect pad needs H,W >= 2");
-    if (L.border && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "border-class bias needs H,W >= 2");
+// plan + launch one (possibly batched) implicit-GEMM described by `a` (M, nkt, cout_pad, nbatch set)
+int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st) {
     int tile, nblocks;
-    plan_conv(M, L.cout_pad, a.nkt, c.tile, &tile, &nblocks, &a.granule);
+    plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, c.tile, &tile, &nblocks, &a.granule);
     int bm, bn;
     igemm_tile_shape(tile, &bm, &bn);
-    a.mtiles = (int)((M + bm - 1) / bm);
-    a.ntiles = L.cout_pad / bn;
-    const long long units = (long long)a.mtiles * a.ntiles * a.nkt;
+    a.mtiles = (a.M + bm - 1) / bm;
+    a.ntiles = a.cout_pad / bn;
+    const long long units = (long long)a.nbatch * a.mtiles * a.ntiles * a.nkt;
     const bool cut = a.granule == 1 && ((units % nblocks) != 0 || ((units / nblocks) % a.nkt) != 0);
     if (cut && (size_t)nblocks * 2 * bm * bn > c.partial_cap) return fail(h, FFR_ERR_NOMEM, "stream-K workspace too small");
     a.partial = c.partial;
     a.tickets = c.tickets;
-    if ((size_t)a.mtiles * a.ntiles > c.tickets_cap) return fail(h, FFR_ERR_NOMEM, "stream-K ticket array too small");
-    const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
-    const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
+    if ((size_t)a.nbatch * a.mtiles * a.ntiles > c.tickets_cap) return fail(h, FFR_ERR_NOMEM, "stream-K ticket array too small");
     static const bool trace_on = getenv("FFR_IGEMM_TRACE") != nullptr;
     if (trace_on) {   // diagnostic: per-block clock sums, printed after a stream sync
         unsigned long long* dbuf = nullptr;
@@ -358,6 +369,54 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     return FFR_OK;
 }
 
+int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
+    IgemmArgs a{};
+    a.x = c.x; a.w = L.w; a.bias = L.bias; a.slope = L.slope; a.resid = c.resid; a.out = c.out; a.zero = h->zero;
+    a.N = c.N; a.H = c.H; a.W = c.W;
+    a.Ho = (c.H + 2 * L.pad - L.R) / L.stride + 1;
+    a.Wo = (c.W + 2 * L.pad - L.S) / L.stride + 1;
+    a.in_pitch = c.in_pitch; a.cin_pad = L.cin_pad; a.R = L.R; a.S = L.S; a.stride = L.stride; a.pad = L.pad;
+    a.pad_mode = L.pad_mode;
+    const long long M = (long long)c.N * a.Ho * a.Wo;
+    if (M <= 0 || M > 0x7fffffffLL) return fail(h, FFR_ERR_ARG, "conv: bad M");
+    a.M = (int)M; a.KK = L.R * L.S * L.cin_pad; a.nkt = a.KK / 32;
+    a.cout_pad = L.cout_pad; a.cout_store = c.cout_store; a.out_pitch = c.out_pitch; a.out_coff = c.out_coff;
+    a.res_pitch = c.res_pitch; a.border_bias = L.border; a.flags = c.flags;
+    if (L.pad_mode == 1 && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "reflect pad needs H,W >= 2");
+    if (L.border && (c.H < 2 || c.W < 2)) return fail(h, FFR_ERR_UNSUPPORTED, "border-class bias needs H,W >= 2");
+    a.nbatch = 1;
+    const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
+    const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
+    static const bool wino_on = !(getenv("FFR_WINO") && atoi(getenv("FFR_WINO")) == 0);
+    if (L.wu && wino_on && c.winoV && c.tile == 0) {
+        // Winograd F(4x4,3x3): input transform -> 36 batched GEMMs [T x cin] * [cin x cout] -> output transform
+        const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
+        const long long T = (long long)c.N * th * tw;
+        if ((size_t)36 * T * L.cin_pad <= c.wino_cap && (size_t)36 * T * L.cout_pad <= c.wino_cap && T < 0x7fffffffLL) {
+            {
+                Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
+                HIPCK(h, launch_wino_in(c.x, c.winoV, c.N, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
+            }
+            IgemmArgs g{};
+            g.x = c.winoV; g.w = L.wu; g.bias = h->zero; g.slope = nullptr; g.resid = nullptr; g.out = c.winoM; g.zero = h->zero;
+            g.N = 1; g.H = 1; g.W = (int)T; g.Ho = 1; g.Wo = (int)T;
+            g.in_pitch = L.cin_pad; g.cin_pad = L.cin_pad; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.pad_mode = 0;
+            g.M = (int)T; g.KK = L.cin_pad; g.nkt = L.cin_pad / 32;
+            g.cout_pad = L.cout_pad; g.cout_store = L.cout_pad; g.out_pitch = L.cout_pad; g.out_coff = 0; g.res_pitch = 0;
+            g.border_bias = 0; g.flags = 0;
+            g.nbatch = 36;
+            g.x_bstride = T * L.cin_pad; g.w_bstride = (long long)L.cout_pad * L.cin_pad; g.out_bstride = T * L.cout_pad;
+            // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
+            RC(run_gemm(h, g, c, flops, bytes, st));
+            Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * T * L.cout_pad + (double)M * L.cout));
+            HIPCK(h, launch_wino_out(c.winoM, L.bias, L.slope, c.resid, c.res_pitch, c.out, c.out_pitch, c.out_coff,
+                                     c.cout_store, L.cout_pad, c.N, c.H, c.W, L.border, c.flags, st));
+            return FFR_OK;
+        }
+    }
+    return run_gemm(h, a, c, flops, bytes, st);
+}
+
 // ---- workspace ---------------------------------------------------------------------------
 struct Arena {
     char* base; size_t off = 0, cap;
@@ -376,6 +435,7 @@ struct Work {
     // shared
     float* partial; size_t partial_cap;
     int* tickets; size_t tickets_cap;
+    float *winoV, *winoM; size_t wino_cap;
     // recnet
     float *X, *bufS, *bufF, *bufM, *s256a, *s256b, *s256c, *ms, *m512a, *m512b, *m512c, *dbg;
     size_t total;
@@ -396,6 +456,15 @@ Work layout(char* base, int N, int H, int W) {
     w.trunk_bn = a.take((size_t)N * hw16 * 512);
     w.partial_cap = (size_t)1024 * 2 * 128 * 128 / 2 + 4096;   // 64 MiB: nblocks * 2 slabs of one tile (fp32)
     w.partial = a.take(w.partial_cap);
+    // Winograd scratch: the largest V / M of the eligible layers (cin >= 256: 14x14x256->512, 7x7x1536)
+    {
+        const size_t t14 = (size_t)N * ((H / 8 + 3) / 4) * ((W / 8 + 3) / 4), t7 = (size_t)N * ((H / 16 + 3) / 4) * ((W / 16 + 3) / 4);
+        size_t cap = 36 * t14 * 512;
+        if (36 * t7 * 1536 > cap) cap = 36 * t7 * 1536;
+        w.wino_cap = cap;
+        w.winoV = a.take(cap);
+        w.winoM = a.take(cap);
+    }
     const size_t P = (size_t)N * 49;
     w.X = a.take(P * 512);
     w.bufS = a.take(P * 576);
@@ -456,12 +525,12 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         ConvCall c1{};
         c1.x = cur; c1.N = N; c1.H = ch; c1.W = cw; c1.in_pitch = b.cin;
         c1.out = w.t1; c1.out_pitch = b.depth; c1.cout_store = b.depth;
-        c1.partial = w.partial; c1.partial_cap = w.partial_cap; c1.tickets = w.tickets; c1.tickets_cap = w.tickets_cap;
+        c1.partial = w.partial; c1.partial_cap = w.partial_cap; c1.tickets = w.tickets; c1.tickets_cap = w.tickets_cap; c1.winoV = w.winoV; c1.winoM = w.winoM; c1.wino_cap = w.wino_cap;
         RC(run_conv(h, b.c1, c1, st));
         ConvCall c2{};
         c2.x = w.t1; c2.N = N; c2.H = ch; c2.W = cw; c2.in_pitch = b.depth;
         c2.out = w.res; c2.out_pitch = b.depth; c2.cout_store = b.depth;
-        c2.partial = w.partial; c2.partial_cap = w.partial_cap; c2.tickets = w.tickets; c2.tickets_cap = w.tickets_cap;
+        c2.partial = w.partial; c2.partial_cap = w.partial_cap; c2.tickets = w.tickets; c2.tickets_cap = w.tickets_cap; c2.winoV = w.winoV; c2.winoM = w.winoM; c2.wino_cap = w.wino_cap;
         RC(run_conv(h, b.c2, c2, st));
         {
             const double e = (double)N * ho * wo * b.depth;
@@ -473,7 +542,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             ConvCall cs{};
             cs.x = cur; cs.N = N; cs.H = ch; cs.W = cw; cs.in_pitch = b.cin;
             cs.out = w.sc; cs.out_pitch = b.depth; cs.cout_store = b.depth;
-            cs.partial = w.partial; cs.partial_cap = w.partial_cap; cs.tickets = w.tickets; cs.tickets_cap = w.tickets_cap;
+            cs.partial = w.partial; cs.partial_cap = w.partial_cap; cs.tickets = w.tickets; cs.tickets_cap = w.tickets_cap; cs.winoV = w.winoV; cs.winoM = w.winoM; cs.wino_cap = w.wino_cap;
             RC(run_conv(h, b.sc, cs, st));
             scp = w.sc;
         }
@@ -504,7 +573,7 @@ int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int 
         ConvCall c{};
         c.x = t; c.N = N; c.H = 1; c.W = 1; c.in_pitch = 25088;
         c.out = w.scale; c.out_pitch = 512; c.cout_store = 512;     // SE scale buffer is free here
-        c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
+        c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap; c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
         RC(run_conv(h, h->fc, c, st));
         Scope s(h, st, FFR_KC_HEAD, 3.0 * N * 512, 8.0 * N * 512);
         HIPCK(h, launch_head_finish(w.scale, 1, N, 512, nullptr, f, st));
@@ -520,7 +589,7 @@ int conv_rec(ffr_handle* h, const Work& w, const ConvW& L, const float* x, int i
     ConvCall c{};
     c.x = x; c.N = N; c.H = 7; c.W = 7; c.in_pitch = in_pitch; c.resid = resid; c.res_pitch = res_pitch;
     c.out = out; c.out_pitch = out_pitch; c.out_coff = out_coff; c.cout_store = L.cout_pad; c.flags = flags;
-    c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
+    c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap; c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
     return run_conv(h, L, c, st);
 }
 
@@ -927,7 +996,7 @@ int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream) {
     ConvCall c{};
     c.x = d->x; c.N = d->N; c.H = d->H; c.W = d->W; c.in_pitch = d->in_pitch; c.resid = d->resid; c.res_pitch = d->res_pitch;
     c.out = d->out; c.out_pitch = d->out_pitch; c.out_coff = d->out_coff; c.cout_store = d->cout_store; c.flags = d->flags;
-    c.tile = d->tile; c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
+    c.tile = d->tile; c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap; c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
     return run_conv(h, L, c, (hipStream_t)stream);
 }
 

@@ -22,6 +22,8 @@ struct IgemmArgs {
     unsigned long long* trace;   // diagnostic (FFR_IGEMM_TRACE): 8 words per block, or null
     int N, H, W, Ho, Wo, in_pitch, cin_pad, R, S, stride, pad, pad_mode;
     int M, KK, nkt, granule;
+    int nbatch;                              // >= 1: independent GEMMs in one launch (tile id = batch-major)
+    long long x_bstride, w_bstride, out_bstride;   // element strides between batches
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch;
     int border_bias, flags;      // flags bit0: sigmoid at the end
     int mtiles, ntiles;
@@ -34,6 +36,15 @@ int igemm_resident_blocks(int tile);
 // persistent stream-K launch over `nblocks` blocks; tiles that are cut are finished inside
 // the launch by the last contributor (a.partial / a.tickets)
 hipError_t launch_igemm(const IgemmArgs& a, int tile, int nblocks, hipStream_t stream);
+
+// ---- Winograd F(4x4,3x3) transforms (winograd.hip) ----------------------------------------
+// V[36][T][cin_pad] = B^T d B of every 6x6 patch (T = N*ceil(H/4)*ceil(W/4)); pad 1, stride 1
+hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
+                          hipStream_t stream);
+// out = epilogue(A^T M A): bias[(border class)][cout_pad], PReLU, residual, sigmoid (flags bit0)
+hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
+                           float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,
+                           int border_bias, int flags, hipStream_t stream);
 
 // ---- trunk elementwise (elementwise.hip) -------------------------------------------
 // stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     // ---- stream-K: this persistent block owns the contiguous range [u, uend) of the
     // launch's (tile, K-tile) units; every block gets the same amount of MFMA work,
     // whatever the tile count is modulo the 256 CUs ----------------------------------------
-    const long long U = (long long)a.mtiles * a.ntiles * a.nkt;
+    const long long U = (long long)a.nbatch * a.mtiles * a.ntiles * a.nkt;
     const long long G = U / a.granule;      // granule = 1, or nkt when tiles are not cut (tiny K)
     long long u = (long long)blockIdx.x * G / gridDim.x * a.granule;
     const long long uend = (long long)(blockIdx.x + 1) * G / gridDim.x * a.granule;
@@ -60,7 +60,14 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     const int kb = (int)(u - (long long)tile_id * a.nkt);
     const int nk = (uend - u < (long long)(a.nkt - kb)) ? (int)(uend - u) : a.nkt - kb;
     u += nk;
-    const int nt = tile_id % a.ntiles, mt = tile_id / a.ntiles;
+    // batched launches (Winograd: 36 GEMMs that differ in A, W and C base) put the batch outermost
+    const int tpb = a.mtiles * a.ntiles;
+    const int batch = tile_id / tpb;
+    const int tile_b = tile_id - batch * tpb;
+    const int nt = tile_b % a.ntiles, mt = tile_b / a.ntiles;
+    const float* const xb = a.x + (long long)batch * a.x_bstride;
+    const float* const wb = a.w + (long long)batch * a.w_bstride;
+    float* const ob = a.out + (long long)batch * a.out_bstride;
     const int m0 = mt * BM, n0 = nt * BN;
     __syncthreads();        // LDS (stages, s_cls) of the previous segment is free
     // the thread id is re-read through an opaque asm every segment: otherwise hipcc hoists every
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     const float* b_ptr[B_PT];
 #pragma unroll
     for (int i = 0; i < B_PT; ++i)
-        b_ptr[i] = a.w + (size_t)(n0 + srow + 32 * i) * a.KK + kbase0 + lch * 4;
+        b_ptr[i] = wb + (size_t)(n0 + srow + 32 * i) * a.KK + kbase0 + lch * 4;
 
     auto set_tap = [&]() {
 #pragma unroll
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
             } else {
                 ok = ((unsigned)hi < (unsigned)a.H) && ((unsigned)wi < (unsigned)a.W);
             }
-            const float* src = a.x + (size_t)(a_pix[i] + hi * a.W + wi) * a.in_pitch;
+            const float* src = xb + (size_t)(a_pix[i] + hi * a.W + wi) * a.in_pitch;
             a_ptr[i] = (ok ? src : a.zero) + c0 + lch * 4;   // the zero page is >= cin_pad floats long
         }
     };
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
                     }
-                    if (m < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)m * a.out_pitch + a.out_coff + n) = v;
+                    if (m < a.M) *reinterpret_cast<f32x4*>(ob + (size_t)m * a.out_pitch + a.out_coff + n) = v;
                 }
                 if (RESID) {
 #pragma unroll
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
                         float x = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
                         if (a.resid) x += a.resid[(size_t)m * a.res_pitch + n + e];
                         if (a.flags & 1) x = 1.0f / (1.0f + __expf(-x));
-                        a.out[(size_t)m * a.out_pitch + a.out_coff + n + e] = x;
+                        ob[(size_t)m * a.out_pitch + a.out_coff + n + e] = x;
                     }
                 }
             }

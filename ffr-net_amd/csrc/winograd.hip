@@ -1,0 +1,182 @@
+// Winograd F(4x4, 3x3) data transforms around the batched fp32-MFMA GEMM (igemm.hip) for the
+// 3x3 / stride 1 / pad 1 convolutions with >= 256 input channels (reference
+// pretrain/model_ir_se50.py:67,69 in stages 3-4 and models/recnet.py:65,82).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray 2016, F(4x4,3x3))
+//
+// 36 multiplies per 4x4 output tile and (cin, cout) pair instead of 144: the matrix cores
+// (the bound of this path, clock-limited) do 1/4 of the direct work (1/3.06 on 7x7 maps, which
+// pad to 8x8); the transforms are HBM-streaming kernels.  fp32 throughout: the measured
+// error of this F(4,3) form is ~2e-6 of the output range at K = 2304 (budget 1e-3).
+//
+//   k_wino_in :  X[N,H,W,pitch] -> V[36][T][cin_pad]      T = N * ceil(H/4) * ceil(W/4) tiles
+//   (igemm)   :  M[xi][T][cout_pad] = V[xi][T][cin_pad] * U[xi][cout_pad][cin_pad]^T, xi = 0..35
+//   k_wino_out:  M -> out[N,H,W,out_pitch] with the conv epilogue (border-class bias, PReLU,
+//                residual, sigmoid)
+#include "ffr_kernels.h"
+
+namespace ffr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v = B^T d
+__device__ __forceinline__ void bt6(const f32x4 d[6], f32x4 v[6]) {
+    v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    v[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+    v[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    v[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    v[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+// y = A^T m
+__device__ __forceinline__ void at6(const f32x4 m[6], f32x4 y[4]) {
+    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.f * d34;
+    y[2] = s12 + 4.f * s34;
+    y[3] = d12 + 8.f * d34 + m[5];
+}
+
+// one thread = one tile x 4 channels; lanes run along the channels (16-B coalesced)
+template <int PAD_MODE>
+__global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int N, int H,
+                                                int W, int pitch, int cin_pad, int th, int tw, long long T) {
+    const int cq = cin_pad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * cq) return;
+    const long long t = idx / cq;
+    const int c4 = (int)(idx - t * cq) * 4;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int n = (int)(t / ((long long)tw * th));
+    const int h0 = ty * 4 - 1, w0 = tx * 4 - 1;
+    const float* xn = x + (size_t)n * H * W * pitch + c4;
+    f32x4 tmp[6][6];
+    // columns first: for every patch column j, transform the 6 rows
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 d[6], v[6];
+        int wi = w0 + j;
+        bool okw = true;
+        if (PAD_MODE == 1) wi = wi < 0 ? -wi : (wi >= W ? 2 * W - 2 - wi : wi);
+        else okw = (unsigned)wi < (unsigned)W;
+        if (PAD_MODE == 1 && wi < 0) wi = 0;      // tiles hanging over the right/bottom edge (outputs dropped)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int hi = h0 + i;
+            bool ok = okw;
+            if (PAD_MODE == 1) { hi = hi < 0 ? -hi : (hi >= H ? 2 * H - 2 - hi : hi); if (hi < 0) hi = 0; }
+            else ok = ok && ((unsigned)hi < (unsigned)H);
+            d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ok) d[i] = *reinterpret_cast<const f32x4*>(xn + ((size_t)hi * W + wi) * pitch);
+        }
+        bt6(d, v);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = v[i];
+    }
+    float* vout = V + (size_t)t * cin_pad + c4;
+    const size_t plane = (size_t)T * cin_pad;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 v[6];
+        bt6(tmp[i], v);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (size_t)(i * 6 + j) * plane) = v[j];
+    }
+}
+
+struct WinoOutArgs {
+    const float* M; const float* bias; const float* slope; const float* resid; float* out;
+    int N, H, W, cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags, th, tw;
+    long long T;
+};
+
+__global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
+    const int cq = a.cout_pad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.T * cq) return;
+    const long long t = idx / cq;
+    const int c4 = (int)(idx - t * cq) * 4;
+    const int tx = (int)(t % a.tw);
+    const int ty = (int)((t / a.tw) % a.th);
+    const int n = (int)(t / ((long long)a.tw * a.th));
+    const float* min = a.M + (size_t)t * a.cout_pad + c4;
+    const size_t plane = (size_t)a.T * a.cout_pad;
+    f32x4 tmp[4][6];      // A^T applied to the columns: [out row][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 m[6], y[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(min + (size_t)(i * 6 + j) * plane);
+        at6(m, y);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tmp[i][j] = y[i];
+    }
+    const bool vec = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0 && c4 + 4 <= a.cout_store;
+    f32x4 slope4 = {1.f, 1.f, 1.f, 1.f};
+    if (a.slope) slope4 = *reinterpret_cast<const f32x4*>(a.slope + c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 y[4];
+        at6(tmp[i], y);
+        const int oh = ty * 4 + i;
+        if (oh >= a.H) continue;
+        const int rc = !a.border_bias ? 0 : (oh == 0 ? 0 : (oh == a.H - 1 ? 2 : 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ow = tx * 4 + j;
+            if (ow >= a.W) continue;
+            const int cls = !a.border_bias ? 0 : rc * 3 + (ow == 0 ? 0 : (ow == a.W - 1 ? 2 : 1));
+            f32x4 v = y[j] + *reinterpret_cast<const f32x4*>(a.bias + (size_t)cls * a.cout_pad + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
+            const size_t m = ((size_t)n * a.H + oh) * a.W + ow;
+            if (vec) {
+                if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + m * a.res_pitch + c4);
+                if (a.flags & 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+                }
+                *reinterpret_cast<f32x4*>(a.out + m * a.out_pitch + a.out_coff + c4) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (c4 + e < a.cout_store) {
+                        float s = v[e];
+                        if (a.resid) s += a.resid[m * a.res_pitch + c4 + e];
+                        if (a.flags & 1) s = 1.0f / (1.0f + __expf(-s));
+                        a.out[m * a.out_pitch + a.out_coff + c4 + e] = s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
+                          hipStream_t stream) {
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)N * th * tw;
+    const long long total = T * (cin_pad >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (pad_mode == 1) hipLaunchKernelGGL(k_wino_in<1>, dim3(blocks), dim3(256), 0, stream, x, V, N, H, W, pitch, cin_pad, th, tw, T);
+    else hipLaunchKernelGGL(k_wino_in<0>, dim3(blocks), dim3(256), 0, stream, x, V, N, H, W, pitch, cin_pad, th, tw, T);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
+                           float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,
+                           int border_bias, int flags, hipStream_t stream) {
+    WinoOutArgs a;
+    a.M = M; a.bias = bias; a.slope = slope; a.resid = resid; a.out = out;
+    a.N = N; a.H = H; a.W = W; a.cout_pad = cout_pad; a.cout_store = cout_store; a.out_pitch = out_pitch;
+    a.out_coff = out_coff; a.res_pitch = res_pitch; a.border_bias = border_bias; a.flags = flags;
+    a.th = (H + 3) / 4; a.tw = (W + 3) / 4;
+    a.T = (long long)N * a.th * a.tw;
+    const long long total = a.T * (cout_pad >> 2);
+    hipLaunchKernelGGL(k_wino_out, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace ffr

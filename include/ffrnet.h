@@ -114,7 +114,8 @@ enum {
     FFR_KC_SPACE = 7,
     FFR_KC_LAYOUT = 8,
     FFR_KC_SCORE = 9,
-    FFR_KC_COUNT = 10
+    FFR_KC_WINO = 10,       /* Winograd F(4x4,3x3) input / output transforms */
+    FFR_KC_COUNT = 11
 };
 typedef struct {
     int64_t launches;
