@@ -287,13 +287,23 @@ void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, i
     const long long big_units = ntiles(best) * nkt;
     const bool large = big_units / (256LL * igemm_resident_blocks(best)) >= (nkt + 3) / 4 && M * nbatch >= 1024;
     if (!large) best = IGEMM_TILE_64x64;
-    if (force_tile >= 1 && force_tile <= IGEMM_NTILES) best = force_tile;
+    bool exact = false;
+    if (large) {
+        // a tile shape whose tile count is a multiple of its persistent block count needs no cut at all
+        for (int t = IGEMM_TILE_128x128; t <= IGEMM_TILE_128x64; ++t) {
+            int bm, bn;
+            igemm_tile_shape(t, &bm, &bn);
+            if (cout_pad % bn) continue;
+            if (ntiles(t) % (256LL * igemm_resident_blocks(t)) == 0) { best = t; exact = true; break; }
+        }
+    }
+    if (force_tile >= 1 && force_tile <= IGEMM_NTILES) { best = force_tile; exact = false; }
     const long long tiles = ntiles(best);
     const long long units = tiles * (long long)nkt;
     const long long pmax = 256LL * igemm_resident_blocks(best);
     long long p;
     *granule = 1;
-    if (nkt < 16 && tiles >= pmax * 8) {        // short K and many tiles per block: whole tiles
+    if (exact || (nkt < 16 && tiles >= pmax && (nkt <= 4 || tiles >= pmax * 8))) {   // whole tiles, nothing is cut
         *granule = nkt;
         p = pmax;
     } else if (large) {

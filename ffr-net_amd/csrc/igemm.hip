@@ -70,6 +70,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     float* const ob = a.out + (long long)batch * a.out_bstride;
     const int m0 = mt * BM, n0 = nt * BN;
     __syncthreads();        // LDS (stages, s_cls) of the previous segment is free
+    // Outside the MFMA loop this wave competes for issue slots with the co-resident block's wave,
+    // which is streaming MFMAs and wins the age-based arbitration: the setup / epilogue VALU and
+    // memory instructions went out at ~1 per MFMA (64 cycles).  Priority 2 for these phases.
+    __builtin_amdgcn_s_setprio(2);
     // the thread id is re-read through an opaque asm every segment: otherwise hipcc hoists every
     // lane-dependent address of the epilogue out of the segment loop and keeps ~100 extra
     // VGPRs alive across the MFMA loop (128x64: 196 instead of ~100 registers -> 2 blocks/CU)
@@ -235,8 +239,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     for (int r = 0; r < NR; ++r) read_piece(0, smem, pc[0], r);
     FFR_PIN;
     if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[1] += t - tr_t; tr_t = t; }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
     for (int it = 0; it + 1 < nk; ++it) tile_body.template operator()<false>(it & 1);
     tile_body.template operator()<true>((nk - 1) & 1);
+    __builtin_amdgcn_s_setprio(2);
     if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[2] += t - tr_t; tr_t = t; }
 #undef FFR_PIN
 
@@ -263,8 +270,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     bool finish = true;                    // this block applies the epilogue and stores the tile
     if (nk != a.nkt) {
         // Partial K range (stream-K cut).  Every contributor stores its raw sums to its slab
-        // (slot 0: segment does not start at k = 0, slot 1: it does), publishes it with an
-        // agent-scope release and draws a ticket; the block that draws the last ticket adds
+        // (slot 0: segment does not start at k = 0, slot 1: it does) with write-through stores,
+        // drains them and draws a ticket; the block that draws the last ticket adds
         // the slabs in block order (bitwise reproducible) and finishes the tile.  Nobody waits.
         const long long tb = (long long)tile_id * a.nkt;
         const int P = gridDim.x;
@@ -273,13 +280,14 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
 #pragma unroll 4
         for (int p = 0; p < BM / RPP; ++p) {
             const int ml = p * RPP + erow;
-            *reinterpret_cast<f32x4*>(dst + ml * BN + ecol) = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+            // write-through (sc1) stores: the slab is in memory once vmcnt drains, so no agent-scope
+            // release (L2 write-back of 64 KB of fresh lines: tens of us per cut) is needed
+            const f32x4 val = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst + ml * BN + ecol), "v"(val) : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains before the barrier
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int old = __hip_atomic_fetch_add(a.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == b_hi - b_lo) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         __syncthreads();
         finish = s_cls[BM] == b_hi - b_lo;
         if (finish) {
-#pragma unroll 2
+#pragma unroll 1
             for (int p = 0; p < BM / RPP; ++p) {
                 const int ml = p * RPP + erow;
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
@@ -309,7 +317,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     }
     if (finish) {
         const int n = n0 + ecol;
-        const bool vec = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0 && n + 4 <= a.cout_store;
+        // (the one sigmoid conv of the network, 49 channels, takes the generic path)
+        const bool vec = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0 && n + 4 <= a.cout_store && !(a.flags & 1);
         f32x4 slope4 = {1.f, 1.f, 1.f, 1.f};
         if (a.slope) slope4 = *reinterpret_cast<const f32x4*>(a.slope + n);
         const f32x4 bias0 = *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -321,12 +330,17 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         constexpr int BATCH = NP < 4 ? NP : 4;
         auto finish_tile = [&]<bool BORDER, bool RESID>() {
             f32x4 rs[BATCH], rn[BATCH];
+            // row pointers advance by RPP rows per pass (no 64-bit multiply per store)
+            const int mrow = m0 + erow;
+            float* optr = ob + (size_t)mrow * a.out_pitch + a.out_coff + n;
+            const size_t ostep = (size_t)RPP * a.out_pitch;
+            const float* rptr = RESID ? a.resid + (size_t)mrow * a.res_pitch + n : nullptr;
+            const size_t rstep = (size_t)RPP * a.res_pitch;
             auto load_resid = [&](f32x4* dstv, int p0) {
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
-                    const int m = m0 + (p0 + k) * RPP + erow;
                     dstv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (m < a.M) dstv[k] = *reinterpret_cast<const f32x4*>(a.resid + (size_t)m * a.res_pitch + n);
+                    if (mrow + (p0 + k) * RPP < a.M) dstv[k] = *reinterpret_cast<const f32x4*>(rptr + (size_t)(p0 + k) * rstep);
                 }
             };
             if (RESID) load_resid(rs, 0);
@@ -336,18 +350,14 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {
                     const int ml = (p0 + k) * RPP + erow;
-                    const int m = m0 + ml;
                     f32x4 v = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
                     if (BORDER) v += *reinterpret_cast<const f32x4*>(s_bias + s_cls[ml] * BN + ecol);
                     else v += bias0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
                     if (RESID) v += rs[k];
-                    if (a.flags & 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
-                    }
-                    if (m < a.M) *reinterpret_cast<f32x4*>(ob + (size_t)m * a.out_pitch + a.out_coff + n) = v;
+                    if (m0 + ml < a.M) *reinterpret_cast<f32x4*>(optr) = v;
+                    optr += ostep;
                 }
                 if (RESID) {
 #pragma unroll
@@ -364,7 +374,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
                 else finish_tile.template operator()<false, false>();
             }
         } else {
-            // generic slow path: channel slices that are not 16-B aligned / ragged cout
+            // generic slow path: channel slices that are not 16-B aligned / ragged cout / sigmoid
+#pragma unroll 1
             for (int p = 0; p < NP; ++p) {
                 const int ml = p * RPP + erow;
                 const int m = m0 + ml;
