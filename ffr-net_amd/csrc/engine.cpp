@@ -46,7 +46,7 @@ struct Block {
 struct ProfRec {
     hipEvent_t e0, e1;
     int kc;
-    double flops, bytes;
+    double flops, bytes, fexec;
 };
 
 }  // namespace
@@ -108,7 +108,8 @@ struct Scope {
     hipStream_t st;
     ProfRec r;
     bool on;
-    Scope(ffr_handle* h_, hipStream_t st_, int kc, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+    Scope(ffr_handle* h_, hipStream_t st_, int kc, double flops, double bytes, double fexec = -1.0)
+        : h(h_), st(st_), on(h_->prof) {
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -116,7 +117,7 @@ struct Scope {
             else hipEventCreate(&e);
             return e;
         };
-        r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes;
+        r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes; r.fexec = fexec < 0 ? flops : fexec;
         hipEventRecord(r.e0, st);
     }
     ~Scope() {
@@ -219,7 +220,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     RC(upload(h, owner, wp, &L->w));
     RC(upload(h, owner, bias, &L->bias));
     L->wu = nullptr;
-    static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 256;
+    static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 128;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
         // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
         static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -329,6 +330,7 @@ struct ConvCall {
     float* partial; size_t partial_cap;   // floats
     int* tickets; size_t tickets_cap;
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
+    int wino_mode = -1;                            // -1 auto (env FFR_WINO), 0 never, 1 whenever packed
 };
 
 // plan + launch one (possibly batched) implicit-GEMM described by `a` (M, nkt, cout_pad, nbatch set)
@@ -373,7 +375,8 @@ int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, doubl
                 tile, nblocks, units, a.nkt, segs / nblocks, acc[0] / segs, acc[1] / segs, acc[2] / segs,
                 acc[2] / ((double)units), acc[3] / segs, e1 / segs, e2 / segs, (double)(r1 - r0) / 100.0, (double)(smax - r0) / 100.0, ghz / nblocks);
     } else {
-        Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes);
+        const double fexec = 2.0 * a.nbatch * (double)a.mtiles * bm * (double)a.cout_pad * a.KK;
+        Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes, fexec);
         HIPCK(h, launch_igemm(a, tile, nblocks, st));
     }
     return FFR_OK;
@@ -398,7 +401,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
     const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
     static const bool wino_on = !(getenv("FFR_WINO") && atoi(getenv("FFR_WINO")) == 0);
-    if (L.wu && wino_on && c.winoV && c.tile == 0) {
+    if (L.wu && c.winoV && c.tile == 0 && (c.wino_mode == 1 || (c.wino_mode < 0 && wino_on))) {
         // Winograd F(4x4,3x3): input transform -> 36 batched GEMMs [T x cin] * [cin x cout] -> output transform
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
         const long long T = (long long)c.N * th * tw;
@@ -466,11 +469,13 @@ Work layout(char* base, int N, int H, int W) {
     w.trunk_bn = a.take((size_t)N * hw16 * 512);
     w.partial_cap = (size_t)1024 * 2 * 128 * 128 / 2 + 4096;   // 64 MiB: nblocks * 2 slabs of one tile (fp32)
     w.partial = a.take(w.partial_cap);
-    // Winograd scratch: the largest V / M of the eligible layers (cin >= 256: 14x14x256->512, 7x7x1536)
+    // Winograd scratch: the largest V / M (36 * tiles * channels) over the layers that may use it
     {
-        const size_t t14 = (size_t)N * ((H / 8 + 3) / 4) * ((W / 8 + 3) / 4), t7 = (size_t)N * ((H / 16 + 3) / 4) * ((W / 16 + 3) / 4);
-        size_t cap = 36 * t14 * 512;
-        if (36 * t7 * 1536 > cap) cap = 36 * t7 * 1536;
+        auto tiles = [&](int div) { return (size_t)N * ((H / div + 3) / 4) * ((W / div + 3) / 4); };
+        size_t cap = 36 * tiles(2) * 128;                                   // 56x56, 64 -> 128 channels
+        if (36 * tiles(4) * 256 > cap) cap = 36 * tiles(4) * 256;           // 28x28, 128 -> 256
+        if (36 * tiles(8) * 512 > cap) cap = 36 * tiles(8) * 512;           // 14x14, 256 -> 512
+        if (36 * tiles(16) * 1536 > cap) cap = 36 * tiles(16) * 1536;       // 7x7, RecNet 1536 -> 512
         w.wino_cap = cap;
         w.winoV = a.take(cap);
         w.winoM = a.take(cap);
@@ -976,7 +981,7 @@ int ffr_profile_enable(ffr_handle* h, int on) {
 
 int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
     if (!h || !out) return fail(h, FFR_ERR_ARG, "ffr_profile_read: bad arguments");
-    for (int i = 0; i < FFR_KC_COUNT; ++i) out[i] = ffr_kclass_stat{0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < FFR_KC_COUNT; ++i) out[i] = ffr_kclass_stat{0, 0.0, 0.0, 0.0, 0.0};
     for (auto& r : h->prof_log) {
         HIPCK(h, hipEventSynchronize(r.e1));
         float ms = 0.f;
@@ -985,6 +990,7 @@ int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
         out[r.kc].ms += ms;
         out[r.kc].flops += r.flops;
         out[r.kc].bytes += r.bytes;
+        out[r.kc].flops_executed += r.fexec;
         h->ev_pool.push_back(r.e0);
         h->ev_pool.push_back(r.e1);
     }
@@ -1008,6 +1014,38 @@ int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream) {
     c.out = d->out; c.out_pitch = d->out_pitch; c.out_coff = d->out_coff; c.cout_store = d->cout_store; c.flags = d->flags;
     c.tile = d->tile; c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap; c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
     return run_conv(h, L, c, (hipStream_t)stream);
+}
+
+int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, const float* w_host,
+                   const float* bias_host, const float* slope_host, int cout, int pad_mode, int use_wino,
+                   const float* resid, float* out, void* stream) {
+    RC(check_fwd(h, false, false, N));
+    if (!x || !w_host || !bias_host || !out || cin % 32 || cout % 4 || cin <= 0 || cout <= 0)
+        return fail(h, FFR_ERR_ARG, "ffr_op_conv3x3: bad arguments (cin %% 32, cout %% 4)");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N > 8 ? N : 8, 112, 112, &w));
+    std::vector<void*> own;
+    BNFold ob;
+    ob.s.assign(cout, 1.0);
+    ob.t.assign(bias_host, bias_host + cout);
+    ConvW L;
+    int rc = pack_conv(h, own, w_host, cout, cin, 3, 3, nullptr, &ob, slope_host, 1, 1, pad_mode, &L);
+    if (rc == FFR_OK && use_wino && !L.wu) rc = fail(h, FFR_ERR_UNSUPPORTED, "layer not eligible for the Winograd path (cin < FFR_WINO_MINCIN)");
+    if (rc == FFR_OK) {
+        ConvCall c{};
+        c.x = x; c.N = N; c.H = H; c.W = W; c.in_pitch = cin; c.resid = resid; c.res_pitch = cout;
+        c.out = out; c.out_pitch = cout; c.out_coff = 0; c.cout_store = cout;
+        c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
+        c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
+        c.wino_mode = use_wino ? 1 : 0;
+        rc = run_conv(h, L, c, st);
+        if (rc == FFR_OK && use_wino && (size_t)36 * N * ((H + 3) / 4) * ((W + 3) / 4) * (L.cin_pad > L.cout_pad ? L.cin_pad : L.cout_pad) > w.wino_cap)
+            rc = fail(h, FFR_ERR_NOMEM, "Winograd scratch too small for this test shape");
+    }
+    hipStreamSynchronize(st);      // the packed weights die with this call
+    free_list(own);
+    return rc;
 }
 
 int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, int n_blocks, float* out, void* stream) {

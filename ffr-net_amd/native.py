@@ -26,7 +26,7 @@ class TensorDesc(C.Structure):
 
 class KClassStat(C.Structure):
     _fields_ = [('launches', C.c_int64), ('ms', C.c_double), ('flops', C.c_double),
-                ('bytes', C.c_double)]
+                ('bytes', C.c_double), ('flops_executed', C.c_double)]
 
 
 class ConvDesc(C.Structure):
@@ -63,6 +63,7 @@ SYMBOLS = [
     ('ffr_profile_enable', C.c_int, [_P, C.c_int]),
     ('ffr_profile_read', C.c_int, [_P, C.POINTER(KClassStat)]),
     ('ffr_op_conv', C.c_int, [_P, C.POINTER(ConvDesc), _P]),
+    ('ffr_op_conv3x3', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ('ffr_encoder_trunk_nhwc', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     ('ffr_recnet_debug', C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
 ]
@@ -247,7 +248,7 @@ class Engine(object):
         arr = (KClassStat * len(KCLASS_NAMES))()
         self._ck(self.lib.ffr_profile_read(self._h, arr))
         return {KCLASS_NAMES[i]: dict(launches=int(arr[i].launches), ms=arr[i].ms,
-                                      flops=arr[i].flops, bytes=arr[i].bytes)
+                                      flops=arr[i].flops, bytes=arr[i].bytes, flops_executed=arr[i].flops_executed)
                 for i in range(len(KCLASS_NAMES))}
 
     # -- test hooks -----------------------------------------------------------
@@ -261,6 +262,24 @@ class Engine(object):
             setattr(d, k, v)
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_op_conv(self._h, C.byref(d), self._stream()))
+
+    def op_conv3x3(self, x_nhwc, w, bias, slope=None, pad_mode=0, use_wino=True, resid=None):
+        """x[N,H,W,cin] device NHWC, w[cout,cin,3,3] / bias / slope host tensors -> out[N,H,W,cout]."""
+        _check_dev(x_nhwc, 'x')
+        x_nhwc = x_nhwc.contiguous()
+        n, hh, ww, cin = x_nhwc.shape
+        wh = w.detach().float().cpu().contiguous()
+        bh = bias.detach().float().cpu().contiguous()
+        sh = slope.detach().float().cpu().contiguous() if slope is not None else None
+        out = torch.empty((n, hh, ww, wh.size(0)), device=x_nhwc.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_op_conv3x3(self._h, _ptr(x_nhwc), n, hh, ww, cin, C.c_void_p(wh.data_ptr()),
+                                             C.c_void_p(bh.data_ptr()),
+                                             C.c_void_p(sh.data_ptr()) if sh is not None else C.c_void_p(0),
+                                             wh.size(0), pad_mode, 1 if use_wino else 0,
+                                             _ptr(resid.contiguous()) if resid is not None else C.c_void_p(0),
+                                             _ptr(out), self._stream()))
+        return out
 
     def encoder_trunk_nhwc(self, x, n_blocks):
         _check_dev(x, 'x')

@@ -101,8 +101,8 @@ int    ffr_reserve(ffr_handle* h, int N, int H, int W);
  * around every launch (bench.py roofline leg; off by default, adds a few us/launch).
  * Classes: see FFR_KC_*.  ffr_profile_read() synchronises the recorded events and
  * returns, per class, the number of launches, the summed device time in ms and the
- * algorithmic FLOPs (2*MACs) and bytes (compulsory in+out+weights) of those launches,
- * then clears the log.                                                              */
+ * algorithmic FLOPs (2*MACs), executed FLOPs and bytes (compulsory in+out+weights) of
+ * those launches, then clears the log.                                                              */
 enum {
     FFR_KC_CONV_IGEMM = 0,  /* fp32-MFMA implicit-GEMM conv / FC (the dominant kernel) */
     FFR_KC_STEM = 1,
@@ -120,8 +120,10 @@ enum {
 typedef struct {
     int64_t launches;
     double  ms;
-    double  flops;
+    double  flops;          /* algorithmic: 2*MACs of the direct convolution / GEMM        */
     double  bytes;
+    double  flops_executed; /* what the matrix cores really did (Winograd F(4x4,3x3) launches
+                               execute 36/144 of the direct MACs, plus tile padding)       */
 } ffr_kclass_stat;
 int ffr_profile_enable(ffr_handle* h, int on);
 int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out /* [FFR_KC_COUNT] */);
@@ -147,6 +149,14 @@ typedef struct {
     int tile, splitk;
 } ffr_conv_desc;
 int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution from RAW weights (host, [cout][cin][3][3] as torch stores them,
+ * bias[cout], optional PReLU slope[cout]) on x[N,H,W,cin] NHWC (device, cin % 32 == 0), packed on
+ * the fly.  use_wino: 1 = Winograd F(4x4,3x3) + batched GEMM, 0 = direct implicit GEMM.  Test hook
+ * that holds both paths to torch's conv2d.  out[N,H,W,cout] NHWC device, cout % 4 == 0.         */
+int ffr_op_conv3x3(ffr_handle* h, const float* x_nhwc, int N, int H, int W, int cin,
+                   const float* w_host, const float* bias_host, const float* slope_host, int cout,
+                   int pad_mode, int use_wino, const float* resid_nhwc, float* out_nhwc, void* stream);
 
 /* Encoder trunk only, stopping after `n_blocks` bottlenecks (0 = stem only,
  * 24 = whole body, before Backbone.bn); writes the NHWC activation.  Test hook for
