@@ -40,6 +40,20 @@ def state_dict_specs():
             {k: tuple(v.shape) for k, v in rec.state_dict().items()})
 
 
+def pmc_traffic():
+    """HBM bytes per k_igemm launch from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes for
+    16-B-per-lane streams on gfx950).  PMC counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')) as f:
+            ig = json.load(f)['igemm']
+        return {'hbm_bytes_per_launch': int(ig['hbm_bytes_per_launch_corrected']),
+                'source': 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, %d launches)'
+                          % ig['launches']}
+    except Exception:
+        return None
+
+
 def host_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota
     (the GPU box shows 256 logical CPUs but grants 16: 256 torch threads there ran the
@@ -164,7 +178,7 @@ def main():
                 'kernel': 'k_igemm (fp32 MFMA implicit GEMM: direct convs, FC and the 36 batched GEMMs of every '
                           'Winograd F(4x4,3x3) conv) + its k_wino_in/k_wino_out transform launches',
                 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
                 'note': 'achieved = algorithmic direct-convolution FLOPs / (k_igemm + transform time); > 1.0 of the '
                         'MFMA peak is possible because Winograd executes 1/4 of the multiplies',
                 'mfma_executed_tflops': round(mfma, 2),
