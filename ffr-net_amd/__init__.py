@@ -9,6 +9,7 @@ from . import synth  # noqa: F401
 from .native import Engine, NativeLibraryMissing, lib_path  # noqa: F401
 from .modules import Backbone, RecNet, ir_se_50_512, l2_norm  # noqa: F401
 from . import lfw  # noqa: F401
+from . import checkpoint  # noqa: F401
 
 __all__ = ['Backbone', 'RecNet', 'ir_se_50_512', 'l2_norm', 'Engine',
-           'NativeLibraryMissing', 'lib_path', 'synth', 'lfw']
+           'NativeLibraryMissing', 'lib_path', 'synth', 'lfw', 'checkpoint']

@@ -21,7 +21,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------
 #define STEM_PIX 64
 #define STEM_STEPS 8
-__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const float* __restrict__ w,
+// U8 = true: the input is the decoded image itself, uint8 [N,H,W,3] RGB, and the reference's input
+// step is applied on the fly (data/dataset.py:70-79, data/dataloader.py:24-28): RGB->BGR channel
+// swap, optional horizontal flip (one flag per image), ToTensor (/255) and Normalize(0.5, 0.5),
+// each in fp32 with the same roundings as torch -> bit-identical stem input, 4x less input traffic.
+template <bool U8>
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const unsigned char* __restrict__ xu8,
+                                             const unsigned char* __restrict__ flip, const float* __restrict__ w,
                                              const float* __restrict__ bias, const float* __restrict__ slope,
                                              float* __restrict__ out, int N, int H, int W) {
     __shared__ __attribute__((aligned(16))) float patch[STEM_PIX * 28];
@@ -50,8 +56,15 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
                 const int h = rem / W, wq = rem - h * W;
                 const int ci = k / 9, r = (k - ci * 9) / 3, s = k - ci * 9 - r * 3;
                 const int hi = h + r - 1, wi = wq + s - 1;
-                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                    v = x[((long long)(n * 3 + ci) * H + hi) * W + wi];
+                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+                    if (U8) {
+                        const int ws = (flip && flip[n]) ? W - 1 - wi : wi;
+                        const float u = (float)xu8[(((long long)n * H + hi) * W + ws) * 3 + (2 - ci)];
+                        v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.5f), 0.5f);
+                    } else {
+                        v = x[((long long)(n * 3 + ci) * H + hi) * W + wi];
+                    }
+                }
             }
             patch[e] = v;
         }
@@ -79,12 +92,13 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     }
 }
 
-hipError_t launch_stem(const float* x, const float* w, const float* bias, const float* slope, float* out,
-                       int N, int H, int W, hipStream_t stream) {
+hipError_t launch_stem(const float* x, const unsigned char* xu8, const unsigned char* flip, const float* w,
+                       const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream) {
     const long long total = (long long)N * H * W;
     const long long per_block = (long long)STEM_PIX * STEM_STEPS;
     const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_stem, dim3(blocks), dim3(256), 0, stream, x, w, bias, slope, out, N, H, W);
+    if (xu8) hipLaunchKernelGGL(k_stem<true>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W);
+    else hipLaunchKernelGGL(k_stem<false>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W);
     return hipGetLastError();
 }
 
@@ -348,6 +362,65 @@ __global__ __launch_bounds__(256) void k_cosine(const float* __restrict__ a, con
 
 hipError_t launch_cosine(const float* a, const float* b, int n, int dim, float* score, hipStream_t stream) {
     hipLaunchKernelGGL(k_cosine, dim3((n + 3) / 4), dim3(256), 0, stream, a, b, n, dim, score);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// LFW fold protocol on the device (lfw/lfw_eval.py:110-118,137-162,255-270): thresholds
+// np.arange(-1, 1, 0.005) bit for bit (numpy fills start + i*delta with delta = (start+step)-start
+// in double, which is 0.005 + 4.4e-18), same iff score > thr, contiguous test folds,
+// best threshold = LAST argmax of the train accuracy, accuracy on the held-out fold.
+//   k_fold_counts: block i = threshold i: correct[i][f] = #correct rows of fold f
+//   k_fold_select: per fold, train count = sum over the other folds; last maximum; test accuracy
+// ---------------------------------------------------------------------------------------
+#define FOLD_MAX 32
+__global__ __launch_bounds__(256) void k_fold_counts(const float* __restrict__ score, const int* __restrict__ label,
+                                                    int n, int nf, double t0, double dt, int* __restrict__ correct) {
+    __shared__ int s_cnt[FOLD_MAX];
+    const int i = blockIdx.x;
+    double prod = (double)i * dt;
+    asm volatile("" : "+v"(prod));          // no fma contraction: numpy rounds the product, then the sum
+    const double thr = t0 + prod;
+    if (threadIdx.x < FOLD_MAX) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += 256) {
+        int f = (int)(((long long)r * nf) / n);
+        while ((long long)(f + 1) * n / nf <= r) ++f;          // fold f holds rows [f*n/nf, (f+1)*n/nf)
+        while ((long long)f * n / nf > r) --f;
+        const int same = ((double)score[r] > thr) ? 1 : 0;
+        if (same == (label[r] == 1 ? 1 : 0)) atomicAdd(&s_cnt[f], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < nf) correct[i * FOLD_MAX + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void k_fold_select(const int* __restrict__ correct, int n, int nf, int nthr, double t0,
+                                                   double dt, double* __restrict__ best_thr, double* __restrict__ test_acc) {
+    const int f = threadIdx.x;
+    if (f >= nf) return;
+    int best_cnt = -1, best_i = 0;
+    for (int i = 0; i < nthr; ++i) {
+        int tot = 0;
+        for (int g = 0; g < nf; ++g) tot += correct[i * FOLD_MAX + g];
+        const int train = tot - correct[i * FOLD_MAX + f];
+        if (train >= best_cnt) { best_cnt = train; best_i = i; }
+    }
+    const int lo = (int)((long long)f * n / nf), hi = (int)((long long)(f + 1) * n / nf);
+    double prod = (double)best_i * dt;
+    asm volatile("" : "+v"(prod));
+    best_thr[f] = t0 + prod;
+    test_acc[f] = (double)correct[best_i * FOLD_MAX + f] / (double)(hi - lo);
+}
+
+hipError_t launch_fold_protocol(const float* score, const int* label, int n, int nf, int* scratch, double* best_thr,
+                                double* test_acc, hipStream_t stream) {
+    if (nf < 1 || nf > FOLD_MAX || n < nf) return hipErrorInvalidValue;
+    const int nthr = 400;     // len(np.arange(-1.0, 1.0, 0.005))
+    volatile double t0 = -1.0, step = 0.005;
+    volatile double next = t0 + step;
+    const double dt = next - t0;     // numpy's arange delta
+    hipLaunchKernelGGL(k_fold_counts, dim3(nthr), dim3(256), 0, stream, score, label, n, nf, (double)t0, dt, scratch);
+    hipLaunchKernelGGL(k_fold_select, dim3(1), dim3(64), 0, stream, scratch, n, nf, nthr, (double)t0, dt, best_thr, test_acc);
     return hipGetLastError();
 }
 

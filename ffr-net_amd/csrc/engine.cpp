@@ -525,11 +525,14 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
 
 // ---- encoder ---------------------------------------------------------------------------
 // Runs stem + n_blocks bottlenecks; *out_ptr = NHWC result, *oh/*ow/*oc its geometry.
+struct U8In { const unsigned char* img; const unsigned char* flip; };
+
 int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, int W, int n_blocks, hipStream_t st,
-              float** out_ptr, int* oh, int* ow, int* oc) {
+              float** out_ptr, int* oh, int* ow, int* oc, const U8In* u8 = nullptr) {
     {
         Scope s(h, st, FFR_KC_STEM, 2.0 * N * H * W * 64 * 27, 4.0 * N * H * W * (3 + 64));
-        HIPCK(h, launch_stem(x_nchw, h->stem_w, h->stem_b, h->stem_s, w.bufA, N, H, W, st));
+        HIPCK(h, launch_stem(x_nchw, u8 ? u8->img : nullptr, u8 ? u8->flip : nullptr, h->stem_w, h->stem_b, h->stem_s,
+                             w.bufA, N, H, W, st));
     }
     float* cur = w.bufA;
     float* nxt = w.bufB;
@@ -575,9 +578,9 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
 
 // trunk -> featmap (NHWC in w.X / w.trunk_bn) and f
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
-                hipStream_t st) {
+                hipStream_t st, const U8In* u8 = nullptr) {
     float* t; int oh, ow, oc;
-    RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc));
+    RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc, u8));
     const int P = oh * ow;
     if (featmap_nhwc) {
         Scope s(h, st, FFR_KC_HEAD, 2.0 * N * P * 512, 8.0 * N * P * 512);
@@ -964,12 +967,37 @@ int ffr_embed(ffr_handle* h, const float* x, int N, float* f_new, float* f, void
     return run_recnet(h, w, N, f_new, nullptr, st);
 }
 
+int ffr_embed_u8(ffr_handle* h, const uint8_t* img_hwc_rgb, const uint8_t* flip, int N, float* f_new, float* f,
+                 void* stream) {
+    RC(check_fwd(h, true, true, N));
+    if (!img_hwc_rgb || !f_new) return fail(h, FFR_ERR_ARG, "img / f_new is null");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, N, 112, 112, &w));
+    U8In u8{img_hwc_rgb, flip};
+    RC(run_encoder(h, w, nullptr, N, 112, 112, w.X, f, st, &u8));
+    return run_recnet(h, w, N, f_new, nullptr, st);
+}
+
 int ffr_cosine_scores(ffr_handle* h, const float* a, const float* b, int n, int dim, float* score, void* stream) {
     RC(check_fwd(h, false, false, n));
     if (!a || !b || !score || dim <= 0) return fail(h, FFR_ERR_ARG, "ffr_cosine_scores: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     Scope s(h, st, FFR_KC_SCORE, 6.0 * n * dim, 8.0 * n * dim);
     HIPCK(h, launch_cosine(a, b, n, dim, score, st));
+    return FFR_OK;
+}
+
+int ffr_lfw_fold_accuracy(ffr_handle* h, const float* score, const int32_t* label, int n, int n_folds, double* best_thr,
+                          double* test_acc, void* stream) {
+    RC(check_fwd(h, false, false, n));
+    if (!score || !label || !best_thr || !test_acc || n_folds < 1 || n_folds > 32 || n < n_folds)
+        return fail(h, FFR_ERR_ARG, "ffr_lfw_fold_accuracy: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, 8, 112, 112, &w));
+    Scope s(h, st, FFR_KC_SCORE, 400.0 * n, 8.0 * 400 * n);
+    HIPCK(h, launch_fold_protocol(score, (const int*)label, n, n_folds, (int*)w.partial, best_thr, test_acc, st));
     return FFR_OK;
 }
 

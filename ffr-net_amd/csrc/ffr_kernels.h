@@ -48,8 +48,10 @@ hipError_t launch_wino_out(const float* M, const float* bias, const float* slope
 
 // ---- trunk elementwise (elementwise.hip) -------------------------------------------
 // stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded
-hipError_t launch_stem(const float* x_nchw, const float* w27x64, const float* bias, const float* slope,
-                       float* out, int N, int H, int W, hipStream_t stream);
+// input: x_nchw fp32, OR (xu8 != null) uint8 [N,H,W,3] RGB images preprocessed on the fly
+// (BGR swap, per-image h-flip flags, /255, (x-0.5)/0.5)
+hipError_t launch_stem(const float* x_nchw, const unsigned char* xu8, const unsigned char* flip, const float* w27x64,
+                       const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream);
 // SE: scale[n][c] = sigmoid(fc2(relu(fc1(mean_hw res[n]))))   fc1 [C/16][C], fc2 [C][C/16]
 // part: scratch [N][se_slices(N,HW)][C] floats (<= N*32*512)
 int se_slices(int N, int HW);
@@ -74,6 +76,10 @@ hipError_t launch_copy_slice(const float* in, float* out, int M, int C, int pitc
                              hipStream_t stream);
 hipError_t launch_cosine(const float* a, const float* b, int n, int dim, float* score,
                          hipStream_t stream);
+
+// LFW fold protocol on device; scratch = 400*32 ints, best_thr/test_acc = nf doubles (device)
+hipError_t launch_fold_protocol(const float* score, const int* label, int n, int nf, int* scratch, double* best_thr,
+                                double* test_acc, hipStream_t stream);
 
 // ---- RecNet operators (recnet_ops.hip) ---------------------------------------------
 // ss_space of models/recnet.py:226-236 for X[N,49,512]; writes bufS[n,j,512+i] = ss[i][j],

@@ -57,7 +57,9 @@ SYMBOLS = [
     ('ffr_encoder_forward', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ('ffr_recnet_forward', C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     ('ffr_embed', C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    ('ffr_embed_u8', C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P]),
     ('ffr_cosine_scores', C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    ('ffr_lfw_fold_accuracy', C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     ('ffr_workspace_bytes', C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_reserve', C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_profile_enable', C.c_int, [_P, C.c_int]),
@@ -221,6 +223,21 @@ class Engine(object):
             self._ck(self.lib.ffr_embed(self._h, _ptr(x), n, _ptr(f_new), _ptr(f), self._stream()))
         return f_new, f
 
+    def embed_u8(self, img, flip=None, want_f=True):
+        """img[N,112,112,3] uint8 RGB (device) -> (f_new, f); flip: optional uint8[N] h-flip flags."""
+        if not (torch.is_tensor(img) and img.is_cuda and img.dtype == torch.uint8):
+            raise RuntimeError('ffrnet_amd: embed_u8 needs a uint8 ROCm device tensor [N,112,112,3]')
+        if img.dim() != 4 or tuple(img.shape[1:]) != (112, 112, 3):
+            raise RuntimeError('ffrnet_amd: embed_u8 expects [N,112,112,3] (HWC, RGB), got %s' % list(img.shape))
+        img = img.contiguous()
+        n = img.size(0)
+        fl = flip.to(device=img.device, dtype=torch.uint8).contiguous() if flip is not None else None
+        f_new = torch.empty((n, 512), device=img.device, dtype=torch.float32)
+        f = torch.empty((n, 512), device=img.device, dtype=torch.float32) if want_f else None
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_embed_u8(self._h, _ptr(img), _ptr(fl), n, _ptr(f_new), _ptr(f), self._stream()))
+        return f_new, f
+
     def cosine_scores(self, a, b):
         _check_dev(a, 'a')
         _check_dev(b, 'b')
@@ -232,6 +249,20 @@ class Engine(object):
             self._ck(self.lib.ffr_cosine_scores(self._h, _ptr(a), _ptr(b), a.size(0), a.size(1),
                                                 _ptr(s), self._stream()))
         return s
+
+    def lfw_fold_accuracy(self, scores, labels, n_folds=10):
+        """Device fold protocol: scores[n] fp32, labels[n] -> (mean accuracy, [(best_thr, acc)] per fold).
+        The mean divides by n_folds (the reference hard-codes 10 = its n_folds)."""
+        _check_dev(scores, 'scores')
+        scores = scores.contiguous()
+        lab = labels.to(device=scores.device, dtype=torch.int32).contiguous()
+        thr = torch.empty(n_folds, device=scores.device, dtype=torch.float64)
+        acc = torch.empty(n_folds, device=scores.device, dtype=torch.float64)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_lfw_fold_accuracy(self._h, _ptr(scores), _ptr(lab), scores.numel(), n_folds,
+                                                    _ptr(thr), _ptr(acc), self._stream()))
+        thr, acc = thr.cpu().tolist(), acc.cpu().tolist()
+        return sum(acc) / n_folds, list(zip(thr, acc))
 
     # -- arena / measurement --------------------------------------------------
     def workspace_bytes(self, n, h=112, w=112):

@@ -85,10 +85,26 @@ int ffr_recnet_forward(ffr_handle* h, const float* featmap_nchw, int N,
 int ffr_embed(ffr_handle* h, const float* x_nchw, int N,
               float* f_new, float* f, void* stream);
 
+/* The same from decoded images: img[N,112,112,3] uint8, HWC, RGB as PIL gives them (device).
+ * The reference's input step runs inside the stem kernel (data/dataset.py:70-79,
+ * data/dataloader.py:24-28): RGB->BGR swap, horizontal flip where flip[n] != 0 (flip may be
+ * NULL; the reference draws ONE flag per pair and applies it to both images), ToTensor (/255),
+ * Normalize(0.5, 0.5) -- bit-identical to feeding ffr_embed the float tensor torch would build. */
+int ffr_embed_u8(ffr_handle* h, const uint8_t* img_hwc_rgb, const uint8_t* flip, int N,
+                 float* f_new, float* f, void* stream);
+
 /* cosine score of lfw/lfw_eval.py:246,248:  sum(a*b) / (|a|*|b| + 1e-8), per row.
  * a, b [n,dim] device fp32 -> score[n] device fp32.                                 */
 int ffr_cosine_scores(ffr_handle* h, const float* a, const float* b, int n, int dim,
                       float* score, void* stream);
+
+/* Fold protocol of lfw/lfw_eval.py:110-118,137-162,255-270 on the device: thresholds
+ * np.arange(-1, 1, 0.005), same iff score > thr, n_folds contiguous test folds (KFold, no shuffle),
+ * best threshold = LAST one reaching the best train accuracy, accuracy on the held-out fold.
+ * score[n] fp32, label[n] int32 (1 = same) device; best_thr[n_folds], test_acc[n_folds] doubles,
+ * device.  n_folds <= 32.  The reference's average is sum(test_acc) / 10.                     */
+int ffr_lfw_fold_accuracy(ffr_handle* h, const float* score, const int32_t* label, int n, int n_folds,
+                          double* best_thr, double* test_acc, void* stream);
 
 /* Device workspace the handle holds / would need for batch N (bytes).  The arena
  * grows on the first call with a larger N (hipMalloc, outside any timed loop) and

@@ -263,3 +263,40 @@ def test_calculate_distance_and_accuracy(engine, golden_dir):
     assert np.abs(pn[:, 0] - g['pred_new'][:, 0]).max() < 1e-4
     assert np.abs(p[:, 0] - g['pred'][:, 0]).max() < 1e-4
     assert np.array_equal(pn[:, 1:], g['pred_new'][:, 1:])
+
+
+def test_device_fold_protocol_matches_reference(engine, golden_dir):
+    """threshold sweep + 10-fold selection on the device, bit-equal to the
+    reference's numbers (golden G5, incl. scores exactly on grid thresholds) and its tie rule."""
+    g = np.load(os.path.join(golden_dir, 'g5_fold_protocol.npz'))
+    scores = torch.from_numpy(g['scores'].astype(np.float32)).cuda()
+    labels = torch.from_numpy(g['labels'].astype(np.int64)).cuda()
+    # the golden was computed on float64 scores; redo the host protocol on the fp32-rounded ones
+    pred = np.array([g['scores'].astype(np.float32).astype(np.float64), g['labels'], np.arange(6000)]).T
+    mean_h, res_h = ffrnet_amd.lfw.get_accuracy_from_predicts(pred)
+    mean_d, res_d = engine.lfw_fold_accuracy(scores, labels, 10)
+    assert [r[0] for r in res_d] == [float(r[0]) for r in res_h]
+    assert [r[1] for r in res_d] == [float(r[1]) for r in res_h]
+    assert abs(mean_d - mean_h) < 1e-15
+    # tie case of the golden: several thresholds reach the best accuracy -> the LAST one wins
+    tie = g['tie']
+    s = torch.from_numpy(tie[:, 0].astype(np.float32)).cuda()
+    lab = torch.from_numpy(tie[:, 1].astype(np.int64)).cuda()
+    _, res = engine.lfw_fold_accuracy(s, lab, 1)        # one fold: train set empty -> every threshold ties at 0
+    assert res[0][0] == float(ffrnet_amd.lfw.THRESHOLDS[-1])
+
+
+def test_uint8_input_step_is_bit_identical(engine):
+    """RGB->BGR, per-image h-flip, ToTensor, Normalize(0.5,0.5) inside the stem kernel
+    (data/dataset.py:70-79, data/dataloader.py:24-28) == the float tensor torch builds, bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    img = torch.randint(0, 256, (6, 112, 112, 3), generator=g, dtype=torch.uint8)      # HWC RGB as PIL gives
+    flip = torch.tensor([0, 1, 0, 1, 1, 0], dtype=torch.uint8)
+    x = img.flip(-1).permute(0, 3, 1, 2).float().div(255)                               # BGR, ToTensor
+    x = (x - 0.5) / 0.5                                                                 # Normalize
+    x = torch.where(flip.view(-1, 1, 1, 1).bool(), x.flip(-1), x).contiguous()          # tf.hflip
+    f_new_a, f_a = engine.embed(x.cuda())
+    f_new_b, f_b = engine.embed_u8(img.cuda(), flip.cuda())
+    assert torch.equal(f_new_a, f_new_b) and torch.equal(f_a, f_b)
+    f_new_c, _ = engine.embed_u8(img.cuda())
+    assert torch.equal(f_new_c[[0, 2, 5]], f_new_a[[0, 2, 5]]) and not torch.equal(f_new_c[1], f_new_a[1])

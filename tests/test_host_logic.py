@@ -141,3 +141,31 @@ def test_sharded_verification_two_ranks_gloo(tmp_path):
     pn, p = ffrnet_amd.lfw.calculate_distance(loader, embed)
     assert np.abs(np.concatenate([pn, p], 1) - r0).max() < 1e-5
     assert 'calls 0 [8, 8, 6]' in logs[0] and 'calls 1 [8, 8, 4]' in logs[1]
+
+
+def test_checkpoint_containers_round_trip(tmp_path, specs):
+    """the reference's two checkpoint containers (plain se50.pth, gzip
+    {'RecNet','optimizer','epoch','iter'}) load into the shells with the reference's semantics."""
+    from ffrnet_amd import checkpoint as ck
+    sd_e = ffrnet_amd.synth.synth_state_dict(specs['encoder'])
+    sd_r = ffrnet_amd.synth.synth_state_dict(specs['recnet'])
+    enc_path = str(tmp_path / 'se50.pth')
+    torch.save(sd_e, enc_path)
+    enc = ffrnet_amd.ir_se_50_512(enc_path)                       # model_ir_se50.py:143-154
+    assert torch.equal(enc.state_dict()['output_layer.3.weight'], sd_e['output_layer.3.weight'])
+    rec = ffrnet_amd.RecNet()
+    rec.load_state_dict(sd_r)
+    os.makedirs(tmp_path / 'ckpt')
+    ck.save_recnet_checkpoint(rec, str(tmp_path / 'ckpt' / '0000400.pth.gzip'), extra_info={'epoch': 3, 'iter': 400})
+    ck.save_recnet_checkpoint(rec, str(tmp_path / 'ckpt' / 'latest.pth.gzip'), extra_info={'epoch': 4, 'iter': 555})
+    assert ck.latest_checkpoint(str(tmp_path / 'ckpt')).endswith('latest.pth.gzip')
+    rec2 = ffrnet_amd.RecNet()
+    pos = ck.load_recnet_checkpoint(rec2, ck.latest_checkpoint(str(tmp_path / 'ckpt')))
+    assert pos == {'epoch': 4, 'iter': 555}
+    for k, v in rec.state_dict().items():
+        assert torch.equal(v, rec2.state_dict()[k]), k
+    # strict=False like the reference: a checkpoint without the classifier still loads
+    w = ck.load(str(tmp_path / 'ckpt' / '0000400.pth.gzip'))
+    del w['RecNet']['classifier.weight']
+    ck.save(w, str(tmp_path / 'noclf.pth.gzip'))
+    ck.load_recnet_checkpoint(ffrnet_amd.RecNet(), str(tmp_path / 'noclf.pth.gzip'))
