@@ -300,3 +300,59 @@ def test_uint8_input_step_is_bit_identical(engine):
     assert torch.equal(f_new_a, f_new_b) and torch.equal(f_a, f_b)
     f_new_c, _ = engine.embed_u8(img.cuda())
     assert torch.equal(f_new_c[[0, 2, 5]], f_new_a[[0, 2, 5]]) and not torch.equal(f_new_c[1], f_new_a[1])
+
+
+def test_verification_accuracy_matches_oracle_small(engine, state_dicts):
+    """BASELINE config 4 in small: pairs -> embeddings -> cosine -> 10-fold protocol; the accuracy
+    from the HIP path equals the one from the oracle's embeddings (identical to 4 dp) and the
+    scores agree to 1e-4."""
+    sd_e, sd_r = state_dicts
+    n_pairs = 100
+    i1, i2, lab = synth.synth_pairs(n_pairs, seed=11, block=10)
+    loader = [dict(img1=i1[s:s + 50].cuda(), img2=i2[s:s + 50].cuda(), label=lab[s:s + 50],
+                   idx=torch.arange(s, s + 50)) for s in (0, 50)]
+    pn, p = ffrnet_amd.lfw.calculate_distance(loader, engine.embed, score_fn=engine.cosine_scores)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    f1n, f1 = O.embed(sd_e, sd_r, i1)
+    f2n, f2 = O.embed(sd_e, sd_r, i2)
+    on = np.array([O.cosine_scores(f1n, f2n).double().numpy(), lab.numpy(), np.arange(n_pairs)]).T
+    oo = np.array([O.cosine_scores(f1, f2).double().numpy(), lab.numpy(), np.arange(n_pairs)]).T
+    assert np.abs(pn[:, 0] - on[:, 0]).max() < 1e-4 and np.abs(p[:, 0] - oo[:, 0]).max() < 1e-4
+    for got, ref in ((pn, on), (p, oo)):
+        a_g, _ = ffrnet_amd.lfw.get_accuracy_from_predicts(got)
+        a_r, _ = ffrnet_amd.lfw.get_accuracy_from_predicts(ref)
+        assert round(a_g, 4) == round(a_r, 4)
+        a_d, _ = engine.lfw_fold_accuracy(torch.from_numpy(got[:, 0].astype(np.float32)).cuda(),
+                                          torch.from_numpy(got[:, 1]).cuda(), 10)
+        a_h, _ = ffrnet_amd.lfw.get_accuracy_from_predicts(
+            np.array([got[:, 0].astype(np.float32).astype(np.float64), got[:, 1], got[:, 2]]).T)
+        assert a_d == a_h
+
+
+def test_full_lfw_size_protocol_properties(engine):
+    """BASELINE config 4 at full size (6000 pairs = 12000 images, batches of 512 pairs): size-independent
+    properties -- finite scores in [-1,1], same-pairs score higher on average, device fold protocol ==
+    host fold protocol on the same scores, embedding of a pair does not depend on its batch."""
+    n_pairs, bs = 6000, 512
+    torch.manual_seed(5)
+    loader = []
+    for s in range(0, n_pairs, bs):
+        m = min(bs, n_pairs - s)
+        a = torch.rand(m, 3, 112, 112, device='cuda') * 2 - 1
+        b = torch.rand(m, 3, 112, 112, device='cuda') * 2 - 1
+        lab = ((torch.arange(s, s + m) % 600) < 300).long()
+        mix = lab.view(-1, 1, 1, 1).cuda().float() * 0.7
+        b = mix * a + (1 - mix) * b
+        loader.append(dict(img1=a, img2=b, label=lab, idx=torch.arange(s, s + m)))
+    pn, p = ffrnet_amd.lfw.calculate_distance(loader, engine.embed, score_fn=engine.cosine_scores)
+    assert pn.shape == (6000, 3) and np.isfinite(pn).all() and np.isfinite(p).all()
+    assert np.abs(pn[:, 0]).max() <= 1.0 + 1e-6 and np.abs(p[:, 0]).max() <= 1.0 + 1e-6
+    assert pn[pn[:, 1] == 1, 0].mean() > pn[pn[:, 1] == 0, 0].mean()
+    acc_h, res_h = ffrnet_amd.lfw.get_accuracy_from_predicts(
+        np.array([pn[:, 0].astype(np.float32).astype(np.float64), pn[:, 1], pn[:, 2]]).T)
+    acc_d, res_d = engine.lfw_fold_accuracy(torch.from_numpy(pn[:, 0].astype(np.float32)).cuda(),
+                                            torch.from_numpy(pn[:, 1]).cuda(), 10)
+    assert acc_d == acc_h and [r[0] for r in res_d] == [float(r[0]) for r in res_h]
+    f_new, _ = engine.embed(loader[3]['img1'][:8].contiguous())
+    f_all, _ = engine.embed(loader[3]['img1'])
+    assert rel(f_all[:8], f_new) < 1e-5
