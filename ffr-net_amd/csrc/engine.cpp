@@ -406,24 +406,40 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
         const long long T = (long long)c.N * th * tw;
         if ((size_t)36 * T * L.cin_pad <= c.wino_cap && (size_t)36 * T * L.cout_pad <= c.wino_cap && T < 0x7fffffffLL) {
-            {
-                Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
-                HIPCK(h, launch_wino_in(c.x, c.winoV, c.N, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
+            // sub-batches: V and M of one slice (36 * tiles * channels * 4 B each) should stay in the
+            // 256 MiB Infinity Cache between the transform that writes them and the kernel that reads them
+            static const long long slice_mb = getenv("FFR_WINO_SLICE_MB") ? atoll(getenv("FFR_WINO_SLICE_MB")) : 0;
+            int nslice = 1;
+            if (slice_mb > 0) {
+                const double mb = 36.0 * T * (L.cin_pad + L.cout_pad) * 4.0 / 1048576.0;
+                while (nslice < c.N && mb / nslice > (double)slice_mb) ++nslice;
+                while (c.N % nslice) ++nslice;
             }
-            IgemmArgs g{};
-            g.x = c.winoV; g.w = L.wu; g.bias = h->zero; g.slope = nullptr; g.resid = nullptr; g.out = c.winoM; g.zero = h->zero;
-            g.N = 1; g.H = 1; g.W = (int)T; g.Ho = 1; g.Wo = (int)T;
-            g.in_pitch = L.cin_pad; g.cin_pad = L.cin_pad; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.pad_mode = 0;
-            g.M = (int)T; g.KK = L.cin_pad; g.nkt = L.cin_pad / 32;
-            g.cout_pad = L.cout_pad; g.cout_store = L.cout_pad; g.out_pitch = L.cout_pad; g.out_coff = 0; g.res_pitch = 0;
-            g.border_bias = 0; g.flags = 0;
-            g.nbatch = 36;
-            g.x_bstride = T * L.cin_pad; g.w_bstride = (long long)L.cout_pad * L.cin_pad; g.out_bstride = T * L.cout_pad;
-            // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
-            RC(run_gemm(h, g, c, flops, bytes, st));
-            Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * T * L.cout_pad + (double)M * L.cout));
-            HIPCK(h, launch_wino_out(c.winoM, L.bias, L.slope, c.resid, c.res_pitch, c.out, c.out_pitch, c.out_coff,
-                                     c.cout_store, L.cout_pad, c.N, c.H, c.W, L.border, c.flags, st));
+            const int Ns = c.N / nslice;
+            const long long Ts = (long long)Ns * th * tw;
+            for (int sl = 0; sl < nslice; ++sl) {
+                const float* xs = c.x + (size_t)sl * Ns * c.H * c.W * c.in_pitch;
+                const float* rs = c.resid ? c.resid + (size_t)sl * Ns * c.H * c.W * c.res_pitch : nullptr;
+                float* os = c.out + (size_t)sl * Ns * c.H * c.W * c.out_pitch;
+                {
+                    Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)Ns * c.H * c.W * L.cin + 36.0 * Ts * L.cin_pad));
+                    HIPCK(h, launch_wino_in(xs, c.winoV, Ns, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
+                }
+                IgemmArgs g{};
+                g.x = c.winoV; g.w = L.wu; g.bias = h->zero; g.slope = nullptr; g.resid = nullptr; g.out = c.winoM; g.zero = h->zero;
+                g.N = 1; g.H = 1; g.W = (int)Ts; g.Ho = 1; g.Wo = (int)Ts;
+                g.in_pitch = L.cin_pad; g.cin_pad = L.cin_pad; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.pad_mode = 0;
+                g.M = (int)Ts; g.KK = L.cin_pad; g.nkt = L.cin_pad / 32;
+                g.cout_pad = L.cout_pad; g.cout_store = L.cout_pad; g.out_pitch = L.cout_pad; g.out_coff = 0; g.res_pitch = 0;
+                g.border_bias = 0; g.flags = 0;
+                g.nbatch = 36;
+                g.x_bstride = Ts * L.cin_pad; g.w_bstride = (long long)L.cout_pad * L.cin_pad; g.out_bstride = Ts * L.cout_pad;
+                // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
+                RC(run_gemm(h, g, c, flops / nslice, bytes / nslice, st));
+                Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * Ts * L.cout_pad + (double)M / nslice * L.cout));
+                HIPCK(h, launch_wino_out(c.winoM, L.bias, L.slope, rs, c.res_pitch, os, c.out_pitch, c.out_coff,
+                                         c.cout_store, L.cout_pad, Ns, c.H, c.W, L.border, c.flags, st));
+            }
             return FFR_OK;
         }
     }

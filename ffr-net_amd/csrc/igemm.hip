@@ -85,17 +85,24 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     // ---- per-thread staging rows -------------------------------------------------
     const int srow = tid >> 3;                              // 0..31
     const int lch = (tid & 7) ^ ((srow >> 1) & 7);          // logical 16-B chunk this lane fetches
-    int a_pix[A_PT], a_hw[A_PT];                            // pixel base, packed (h0 << 16) | (w0 & 0xffff)
+    int a_pix[A_PT], a_h0[A_PT], a_w0[A_PT];                // pixel base of the image, top-left tap coordinates
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
         int m = m0 + srow + 32 * i;
         if (m >= a.M) m = 0;                                // rows past M compute garbage, never stored
-        const int n = m / HoWo;
-        const int rem = m - n * HoWo;
-        const int ho = rem / a.Wo;
-        const int wo = rem - ho * a.Wo;
-        a_pix[i] = n * a.H * a.W;
-        a_hw[i] = ((ho * a.stride - a.pad) << 16) | ((wo * a.stride - a.pad) & 0xffff);
+        if (a.H == 1 && a.N == 1) {                         // plain GEMM rows (FC, Winograd GEMMs): no division
+            a_pix[i] = 0;
+            a_h0[i] = -a.pad;
+            a_w0[i] = m * a.stride - a.pad;
+        } else {
+            const int n = m / HoWo;
+            const int rem = m - n * HoWo;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            a_pix[i] = n * a.H * a.W;
+            a_h0[i] = ho * a.stride - a.pad;
+            a_w0[i] = wo * a.stride - a.pad;
+        }
     }
     if (a.border_bias && tid < BM) {
         int m = m0 + tid;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     auto set_tap = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
-            int hi = (a_hw[i] >> 16) + tr, wi = (int)(short)(a_hw[i] & 0xffff) + ts;
+            int hi = a_h0[i] + tr, wi = a_w0[i] + ts;
             bool ok = true;
             if (PAD_MODE == 1) {
                 hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi);

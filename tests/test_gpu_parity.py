@@ -113,6 +113,7 @@ WINO_CASES = [
     (5, 7, 7, 512, 512, 1, True, True),       # 7x7: tiles hang over the edge, reflect padding
     (2, 13, 10, 128, 64, 0, True, True),      # ragged H, W
     (4, 7, 7, 576, 256, 1, True, False),
+    (700, 28, 28, 128, 64, 0, False, False),  # 34300 tiles: GEMM rows beyond 2^15
 ]
 
 
