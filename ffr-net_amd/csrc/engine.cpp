@@ -425,6 +425,35 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)Ns * c.H * c.W * L.cin + 36.0 * Ts * L.cin_pad));
                     HIPCK(h, launch_wino_in(xs, c.winoV, Ns, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
                 }
+                // 36 GEMMs [Ts x cin] * [cin x cout] in one persistent launch with a continuous K-tile stream;
+                // tile shape: fewest rounds of whole tiles over the resident blocks, weighted by loop efficiency
+                static const bool use_stream = !(getenv("FFR_GEMM_STREAM") && atoi(getenv("FFR_GEMM_STREAM")) == 0);
+                if (use_stream) {
+                    int gtile = IGEMM_TILE_128x64, gblocks = 768;
+                    double best = 1e300;
+                    for (int tt = IGEMM_TILE_128x128; tt <= IGEMM_TILE_128x64; ++tt) {
+                        int bm, bn;
+                        igemm_tile_shape(tt, &bm, &bn);
+                        if (L.cout_pad % bn) continue;
+                        const long long tiles = 36LL * ((Ts + bm - 1) / bm) * (L.cout_pad / bn);
+                        const long long pmax = 256LL * igemm_resident_blocks(tt);
+                        const long long p = pmax > tiles ? tiles : pmax;
+                        const double rounds = (double)((tiles + p - 1) / p);
+                        // (measured: 128x64 wins whenever it divides evenly, although its loop is less efficient)
+                        const double cost = rounds * bm * bn * ((double)pmax / p) / (tt == IGEMM_TILE_128x128 ? 1.0 : 0.92);
+                        if (cost < best) { best = cost; gtile = tt; gblocks = (int)p; }
+                    }
+                    GemmStreamArgs g{};
+                    g.A = c.winoV; g.W = L.wu; g.C = c.winoM; g.M = (int)Ts; g.K = L.cin_pad; g.Npad = L.cout_pad; g.nbatch = 36;
+                    static const int ablate = getenv("FFR_GS_ABLATE") ? atoi(getenv("FFR_GS_ABLATE")) : 0;
+                    g.ablate = ablate;
+                    int bm, bn;
+                    igemm_tile_shape(gtile, &bm, &bn);
+                    const double fexec = 2.0 * 36.0 * (double)((Ts + bm - 1) / bm) * bm * (double)L.cout_pad * L.cin_pad;
+                    // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
+                    Scope s(h, st, FFR_KC_CONV_IGEMM, flops / nslice, bytes / nslice, fexec);
+                    HIPCK(h, launch_gemm_stream(g, gtile, gblocks, st));
+                } else {
                 IgemmArgs g{};
                 g.x = c.winoV; g.w = L.wu; g.bias = h->zero; g.slope = nullptr; g.resid = nullptr; g.out = c.winoM; g.zero = h->zero;
                 g.N = 1; g.H = 1; g.W = (int)Ts; g.Ho = 1; g.Wo = (int)Ts;
@@ -436,6 +465,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 g.x_bstride = Ts * L.cin_pad; g.w_bstride = (long long)L.cout_pad * L.cin_pad; g.out_bstride = Ts * L.cout_pad;
                 // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
                 RC(run_gemm(h, g, c, flops / nslice, bytes / nslice, st));
+                }
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * Ts * L.cout_pad + (double)M / nslice * L.cout));
                 HIPCK(h, launch_wino_out(c.winoM, L.bias, L.slope, rs, c.res_pitch, os, c.out_pitch, c.out_coff,
                                          c.cout_store, L.cout_pad, Ns, c.H, c.W, L.border, c.flags, st));
@@ -725,6 +755,7 @@ int ffr_create(ffr_handle** out, int device) {
     hipMemset(z, 0, 131072);
     h->zero = (float*)z;
     hipError_t e = igemm_init();
+    if (e == hipSuccess) e = gemm_stream_init();
     if (e != hipSuccess) {
         hipFree(z); delete h;
         return fail(nullptr, FFR_ERR_HIP, "igemm_init: %s", hipGetErrorString(e));

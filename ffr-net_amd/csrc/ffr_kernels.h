@@ -37,6 +37,17 @@ int igemm_resident_blocks(int tile);
 // the launch by the last contributor (a.partial / a.tickets)
 hipError_t launch_igemm(const IgemmArgs& a, int tile, int nblocks, hipStream_t stream);
 
+// ---- batched plain GEMM with a continuous K-tile stream (gemm_stream.hip) -------------------
+// C[b][m][n] = sum_k A[b][m][k] * W[b][n][k];  A [nbatch][M][K], W [nbatch][Npad][K], C [nbatch][M][Npad]
+struct GemmStreamArgs {
+    const float* A; const float* W; float* C;
+    int M, K, Npad, nbatch;
+    int mtiles, ntiles;      // filled by the launcher
+    int ablate;              // timing experiments only (tools/): bit0 = skip the stores
+};
+hipError_t gemm_stream_init();
+hipError_t launch_gemm_stream(GemmStreamArgs a, int tile, int nblocks, hipStream_t stream);
+
 // ---- Winograd F(4x4,3x3) transforms (winograd.hip) ----------------------------------------
 // V[36][T][cin_pad] = B^T d B of every 6x6 patch (T = N*ceil(H/4)*ceil(W/4)); pad 1, stride 1
 hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
