@@ -175,8 +175,8 @@ def main():
         ach = c['flops'] / (conv_ms * 1e-3) / 1e12       # ALGORITHMIC (direct-conv) FLOPs, SURVEY 8(d)
         mfma = c['flops_executed'] / (c['ms'] * 1e-3) / 1e12
         roof = {'bound': 'mfma',
-                'kernel': 'k_igemm (fp32 MFMA implicit GEMM: direct convs, FC and the 36 batched GEMMs of every '
-                          'Winograd F(4x4,3x3) conv) + its k_wino_in/k_wino_out transform launches',
+                'kernel': 'k_igemm / k_gemm_stream (fp32 MFMA implicit GEMM: direct convs, FC, and the 36 batched GEMMs of '
+                          'every Winograd F(4x4,3x3) conv) + the k_wino_in/k_wino_out transform launches',
                 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
                 'note': 'achieved = algorithmic direct-convolution FLOPs / (k_igemm + transform time); > 1.0 of the '

@@ -13,7 +13,7 @@ tot = collections.defaultdict(lambda: [0.0, 0])
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob('$R/gpurun_out/pmc_bench/%s/*/*counter_collection.csv' % c):
         for r in csv.DictReader(open(f)):
-            k = 'igemm' if 'k_igemm' in r['Kernel_Name'] else r['Kernel_Name'].split('(')[0][-40:]
+            k = 'igemm' if ('k_igemm' in r['Kernel_Name'] or 'k_gemm_stream' in r['Kernel_Name']) else r['Kernel_Name'].split('(')[0][-40:]
             if r['Counter_Name'] == c:
                 tot[(k, c)][0] += float(r['Counter_Value']); tot[(k, c)][1] += 1
 out = {}
