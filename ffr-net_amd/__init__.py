@@ -6,10 +6,10 @@ the C-ABI library libffrnet_hip.so (include/ffrnet.h).  There is no CPU fallback
 forward without the HIP library or on a non-ROCm tensor raises.
 """
 from . import synth  # noqa: F401
-from .native import Engine, NativeLibraryMissing, lib_path  # noqa: F401
+from .native import Engine, GraphedEmbed, NativeLibraryMissing, lib_path  # noqa: F401
 from .modules import Backbone, RecNet, ir_se_50_512, l2_norm  # noqa: F401
 from . import lfw  # noqa: F401
 from . import checkpoint  # noqa: F401
 
-__all__ = ['Backbone', 'RecNet', 'ir_se_50_512', 'l2_norm', 'Engine',
+__all__ = ['Backbone', 'RecNet', 'ir_se_50_512', 'l2_norm', 'Engine', 'GraphedEmbed',
            'NativeLibraryMissing', 'lib_path', 'synth', 'lfw', 'checkpoint']

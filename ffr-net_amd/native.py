@@ -341,3 +341,35 @@ class Engine(object):
                 _ptr(o['feat_space']), _ptr(o['feat_channel_raw']), _ptr(o['feat_channel']),
                 self._stream()))
         return o
+
+
+class GraphedEmbed(object):
+    """hipGraph replay of Engine.embed for a fixed batch size (small batches are launch bound: one
+    forward is ~190 launches).  The whole forward is enqueued by ONE ffr_embed call that neither
+    allocates nor synchronises once the workspace is reserved, so it captures as is.
+        g = GraphedEmbed(engine, n);  f_new, f = g(x)       # x[n,3,112,112] on the device
+    The returned tensors are the graph's static outputs (overwritten by the next call)."""
+
+    def __init__(self, engine, n):
+        self.engine, self.n = engine, n
+        dev = engine.device
+        engine.reserve(n)
+        self.x = torch.zeros((n, 3, 112, 112), device=dev, dtype=torch.float32)
+        self.f_new = torch.empty((n, 512), device=dev, dtype=torch.float32)
+        self.f = torch.empty((n, 512), device=dev, dtype=torch.float32)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up outside the capture
+            engine.embed(self.x, out=(self.f_new, self.f))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            engine.embed(self.x, out=(self.f_new, self.f))
+
+    def __call__(self, x):
+        _check_dev(x, 'x', (3, 112, 112))
+        if x.size(0) != self.n:
+            raise RuntimeError('GraphedEmbed was captured for batch %d, got %d' % (self.n, x.size(0)))
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.f_new, self.f

@@ -357,3 +357,18 @@ def test_full_lfw_size_protocol_properties(engine):
     f_new, _ = engine.embed(loader[3]['img1'][:8].contiguous())
     f_all, _ = engine.embed(loader[3]['img1'])
     assert rel(f_all[:8], f_new) < 1e-5
+
+
+def test_hipgraph_replay_matches_eager(engine):
+    """One forward is a single launch-only C call: it captures into a hipGraph; replay == eager."""
+    x = synth.synth_images(8, seed=31).cuda()
+    f_new, f = engine.embed(x)
+    g = ffrnet_amd.GraphedEmbed(engine, 8)
+    for _ in range(2):
+        g_new, g_f = g(x)
+        torch.cuda.synchronize()
+        assert torch.equal(g_new, f_new) and torch.equal(g_f, f)
+    x2 = synth.synth_images(8, seed=32).cuda()
+    h_new, _ = g(x2)
+    e_new, _ = engine.embed(x2)
+    assert torch.equal(h_new, e_new)
