@@ -954,6 +954,18 @@ int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n) {
     RC(upload(h, own, std::vector<float>(a7, a7 + 512), &p)); cw.a7 = p;
     RC(upload(h, own, std::vector<float>(W8, W8 + 512 * 32), &p)); cw.w8 = p;
     RC(upload(h, own, std::vector<float>(b8, b8 + 512), &p)); cw.b8 = p;
+    {   // MFMA operand orders of the last linear (k_channel_path P5)
+        std::vector<float> w8a((size_t)16 * 64 * 16), b8a((size_t)16 * 2 * 16);
+        for (int t = 0; t < 16; ++t) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int ks = 0; ks < 16; ++ks)
+                    w8a[((size_t)t * 64 + lane) * 16 + ks] = W8[(size_t)(32 * t + (lane & 31)) * 32 + 2 * ks + (lane >> 5)];
+            for (int hh = 0; hh < 2; ++hh)
+                for (int r = 0; r < 16; ++r) b8a[((size_t)t * 2 + hh) * 16 + r] = b8[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh];
+        }
+        RC(upload(h, own, w8a, &p)); cw.w8a = p;
+        RC(upload(h, own, b8a, &p)); cw.b8a = p;
+    }
     h->rec_loaded = true;
     return FFR_OK;
 }

@@ -110,6 +110,8 @@ struct ChannelPathWeights {   // device pointers, see engine.cpp pack_recnet()
     const float* a7;    // [512]
     const float* w8;    // [512][32] Conv4Channel.8.weight
     const float* b8;    // [512]
+    const float* w8a;   // [16][64][16]  w8 in MFMA A-operand order: [c' tile][lane][k-step] = w8[32t + (lane&31)][2ks + (lane>>5)]
+    const float* b8a;   // [16][2][16]   b8 in accumulator order: [c' tile][lane>>5][reg] = b8[32t + (r&3) + 8(r>>2) + 4h]
 };
 // feat_channel_raw[c][p] = sum_c' sigmoid(Conv4Channel(..))[c][c'] X[c'][p]; written to
 // bufF[n,p,512+c] and W-flipped to bufF[n,flip(p),c]  (bufF pitch 1024)

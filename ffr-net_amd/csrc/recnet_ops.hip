@@ -89,7 +89,7 @@ hipError_t launch_selfsim_space(const float* X, float* bufS, int pitchS, float* 
 //     running product with X, so M_channel (268 MB) is never stored either.
 // ---------------------------------------------------------------------------------------
 #define XT_LD 52
-__global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ X, const ChannelPathWeights w,
+__global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict__ X, const ChannelPathWeights w,
                                                      const float* __restrict__ w1bT, float* __restrict__ bufF,
                                                      int pitchF) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ 
     float* G = inv + 512;                 // [49][32]
     const int n = blockIdx.x, tid = threadIdx.x;
     const float* Xn = X + (size_t)n * 49 * 512;
-    const int c0 = tid, c1 = tid + 256;
+    const int c0 = tid, c1 = tid + 256;                       // columns this thread transposes in P1
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r0 = 128 * wave + lane, r1 = r0 + 64;           // rows whose MLP this thread evaluates (P3, P4)
 
     {   // P1: transpose into LDS + channel norms
         float s0 = 0.f, s1 = 0.f;
@@ -124,11 +126,11 @@ __global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ 
     __syncthreads();
     // P3: h[j] = b1[j] + sum_p X[p][c] * (W1a[j][p] + inv_c * G[p][j])
     float h0[32], h1[32];
-    const float i0 = inv[c0], i1 = inv[c1];
+    const float i0 = inv[r0], i1 = inv[r1];
 #pragma unroll
     for (int j = 0; j < 32; ++j) { h0[j] = w.b1[j]; h1[j] = w.b1[j]; }
     for (int p = 0; p < 49; ++p) {
-        const float x0 = XT[c0 * XT_LD + p], x1 = XT[c1 * XT_LD + p];
+        const float x0 = XT[r0 * XT_LD + p], x1 = XT[r1 * XT_LD + p];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             const float wa = w.w1a[j * 49 + p], g = G[p * 32 + j];
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ 
     }
     // P4: PReLU (slope per row c), two folded 32x32 affines with PReLU after each
     {
-        const float s0 = w.a1[c0], s1 = w.a1[c1];
+        const float s0 = w.a1[r0], s1 = w.a1[r1];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             h0[j] = h0[j] >= 0.f ? h0[j] : h0[j] * s0;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ 
         const float* A = layer == 0 ? w.A2 : w.A3;
         const float* d = layer == 0 ? w.d2 : w.d3;
         const float* sl = layer == 0 ? w.a4 : w.a7;
-        const float s0 = sl[c0], s1 = sl[c1];
+        const float s0 = sl[r0], s1 = sl[r1];
         float t0[32], t1[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
@@ -167,41 +169,84 @@ __global__ __launch_bounds__(256) void k_channel_path(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 32; ++j) { h0[j] = t0[j]; h1[j] = t1[j]; }
     }
-    // P5: for every column c': m = sigmoid(w8[c'] . h + b8[c']);  acc[p] += m * X[p][c']
-    float acc0[XT_LD], acc1[XT_LD];
+    // P5 (matrix cores): per 32-column tile of c' and 32-row tile of c
+    //   Zt[c'][c]  = W8[c'][:] . h3[c][:] + b8[c']            16 x v_mfma_f32_32x32x2_f32  (A = W8 tile, B = h3^T)
+    //   Mt         = sigmoid(Zt)                              = M_channel[c][c'] transposed, in accumulator layout
+    //   fcT[p][c] += X[p][c'] * Mt[c'][c]                     2 x 16 MFMAs; the accumulator tile Mt IS the B operand:
+    //       k-step r feeds register r (lanes 0-31 hold row (r&3)+8(r>>2), lanes 32-63 that row + 4), A = X^T from LDS
+    // Wave w owns rows c in [128w, 128w+128) = 4 column tiles of the MFMA output.
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int mj = lane & 31, mh = lane >> 5;
+    float HB[4][16];
 #pragma unroll
-    for (int p = 0; p < XT_LD; ++p) { acc0[p] = 0.f; acc1[p] = 0.f; }
+    for (int ks = 0; ks < 16; ++ks) {
+        // h3 of row 128w + 32ct + mj lives in lane (32*(ct&1) + mj), array h0 (ct < 2) or h1 (ct >= 2)
+        const float e0 = __shfl(h0[2 * ks], mj, 64), o0 = __shfl(h0[2 * ks + 1], mj, 64);
+        const float e1 = __shfl(h0[2 * ks], 32 + mj, 64), o1 = __shfl(h0[2 * ks + 1], 32 + mj, 64);
+        const float e2 = __shfl(h1[2 * ks], mj, 64), o2 = __shfl(h1[2 * ks + 1], mj, 64);
+        const float e3 = __shfl(h1[2 * ks], 32 + mj, 64), o3 = __shfl(h1[2 * ks + 1], 32 + mj, 64);
+        HB[0][ks] = mh ? o0 : e0;
+        HB[1][ks] = mh ? o1 : e1;
+        HB[2][ks] = mh ? o2 : e2;
+        HB[3][ks] = mh ? o3 : e3;
+    }
+    f32x16 fc[4][2];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fc[ct][pt][r] = 0.f;
+    const int p_lo = mj, p_hi = (32 + mj) < 51 ? (32 + mj) : 51;        // XT[..][49..51] are zeros
 #pragma unroll 1
-    for (int cp = 0; cp < 512; ++cp) {
-        float z0 = w.b8[cp], z1 = z0;
+    for (int cpt = 0; cpt < 16; ++cpt) {
+        float wa[16], bz[16], xa[2][16];
+        const f32x4* wp = reinterpret_cast<const f32x4*>(w.w8a + ((size_t)cpt * 64 + lane) * 16);
+        const f32x4* bp = reinterpret_cast<const f32x4*>(w.b8a + ((size_t)cpt * 2 + mh) * 16);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const float wv = w.w8[cp * 32 + i];
-            z0 += wv * h0[i];
-            z1 += wv * h1[i];
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = wp[q], bv = bp[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wa[q * 4 + e] = wv[e]; bz[q * 4 + e] = bv[e]; }
         }
-        const float m0 = 1.0f / (1.0f + __expf(-z0));
-        const float m1 = 1.0f / (1.0f + __expf(-z1));
-        const f32x4* xr = reinterpret_cast<const f32x4*>(XT + cp * XT_LD);
 #pragma unroll
-        for (int q = 0; q < XT_LD / 4; ++q) {
-            const f32x4 xv = xr[q];
+        for (int r = 0; r < 16; ++r) {
+            const int cprow = cpt * 32 + (r & 3) + 8 * (r >> 2) + 4 * mh;
+            xa[0][r] = XT[cprow * XT_LD + p_lo];
+            xa[1][r] = XT[cprow * XT_LD + p_hi];
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0[q * 4 + e] += m0 * xv[e];
-                acc1[q * 4 + e] += m1 * xv[e];
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = bz[r];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) z = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ks], HB[ct][ks], z, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 1.0f / (1.0f + __expf(-z[r]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                fc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[0][r], z[r], fc[ct][0], 0, 0, 0);
+                fc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[1][r], z[r], fc[ct][1], 0, 0, 0);
             }
         }
     }
     // P6: feat_channel at channels [512,1024), its W-flip (torch.flip(.,[3])) at [0,512)
     float* Fn = bufF + (size_t)n * 49 * pitchF;
 #pragma unroll
-    for (int p = 0; p < 49; ++p) {
-        const int pf = (p / 7) * 7 + (6 - p % 7);
-        Fn[p * pitchF + 512 + c0] = acc0[p];
-        Fn[p * pitchF + 512 + c1] = acc1[p];
-        Fn[pf * pitchF + c0] = acc0[p];
-        Fn[pf * pitchF + c1] = acc1[p];
+    for (int ct = 0; ct < 4; ++ct) {
+        const int c = 128 * wave + 32 * ct + mj;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * mh;
+                if (p < 49) {
+                    const int pf = (p / 7) * 7 + (6 - p % 7);
+                    Fn[p * pitchF + 512 + c] = fc[ct][pt][r];
+                    Fn[pf * pitchF + c] = fc[ct][pt][r];
+                }
+            }
     }
 }
 
