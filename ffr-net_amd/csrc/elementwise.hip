@@ -41,32 +41,42 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     const f32x4 b = *reinterpret_cast<const f32x4*>(bias + cg * 4);
     const f32x4 sl = *reinterpret_cast<const f32x4*>(slope + cg * 4);
 
+    int f_ci[7], f_dr[7], f_ds[7];          // tap geometry of this thread's 7 fill slots
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int k = (tid & 3) * 7 + i;
+        f_ci[i] = k / 9;                     // 3 = the padding slot k == 27
+        f_dr[i] = (k - f_ci[i] * 9) / 3 - 1;
+        f_ds[i] = k % 3 - 1;
+    }
     for (int step = 0; step < STEM_STEPS; ++step) {
         const long long p0 = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX;
         if (p0 >= total) break;
         __syncthreads();
-        // fill: element e = pix*28 + k, k = (ci*3 + r)*3 + s   (k == 27 is padding)
-        for (int e = tid; e < STEM_PIX * 28; e += 256) {
-            const int pix = e / 28, k = e - pix * 28;
-            float v = 0.f;
+        // fill: 4 threads per pixel, 7 taps each (k = (ci*3 + r)*3 + s, k == 27 is padding): ONE pixel
+        // decomposition per thread and step; the tap geometry of a thread never changes
+        {
+            const int pix = tid >> 2;
             const long long p = p0 + pix;
-            if (k < 27 && p < total) {
-                const int n = (int)(p / HW);
-                const int rem = (int)(p - (long long)n * HW);
-                const int h = rem / W, wq = rem - h * W;
-                const int ci = k / 9, r = (k - ci * 9) / 3, s = k - ci * 9 - r * 3;
-                const int hi = h + r - 1, wi = wq + s - 1;
-                if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+            const bool pv = p < total;
+            const int n = pv ? (int)(p / HW) : 0;
+            const int rem = pv ? (int)(p - (long long)n * HW) : 0;
+            const int h = rem / W, wq = rem - h * W;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                float v = 0.f;
+                const int hi = h + f_dr[i], wi = wq + f_ds[i];
+                if (pv && f_ci[i] < 3 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
                     if (U8) {
                         const int ws = (flip && flip[n]) ? W - 1 - wi : wi;
-                        const float u = (float)xu8[(((long long)n * H + hi) * W + ws) * 3 + (2 - ci)];
+                        const float u = (float)xu8[(((long long)n * H + hi) * W + ws) * 3 + (2 - f_ci[i])];
                         v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.5f), 0.5f);
                     } else {
-                        v = x[((long long)(n * 3 + ci) * H + hi) * W + wi];
+                        v = x[((long long)(n * 3 + f_ci[i]) * H + hi) * W + wi];
                     }
                 }
+                patch[pix * 28 + (tid & 3) * 7 + i] = v;
             }
-            patch[e] = v;
         }
         __syncthreads();
 #pragma unroll

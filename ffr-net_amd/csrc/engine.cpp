@@ -439,9 +439,20 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                         const long long pmax = 256LL * igemm_resident_blocks(tt);
                         const long long p = pmax > tiles ? tiles : pmax;
                         const double rounds = (double)((tiles + p - 1) / p);
-                        // (measured: 128x64 wins whenever it divides evenly, although its loop is less efficient)
-                        const double cost = rounds * bm * bn * ((double)pmax / p) / (tt == IGEMM_TILE_128x128 ? 1.0 : 0.92);
+                        // a block gets 1/R of its CU (R co-resident blocks), so a round of tiles costs bm*bn*R;
+                        // the 128x64 loop runs at ~92% of the 128x128 loop's rate (measured per layer, r01 traces)
+                        const double share = (double)((p + 255) / 256);
+                        const double cost = rounds * bm * bn * share / (tt == IGEMM_TILE_128x128 ? 1.0 : 0.92);
                         if (cost < best) { best = cost; gtile = tt; gblocks = (int)p; }
+                    }
+                    static const int force_gs = getenv("FFR_GS_TILE") ? atoi(getenv("FFR_GS_TILE")) : 0;
+                    if ((force_gs == IGEMM_TILE_128x128 && L.cout_pad % 128 == 0) || force_gs == IGEMM_TILE_128x64) {
+                        gtile = force_gs;
+                        int bm, bn;
+                        igemm_tile_shape(gtile, &bm, &bn);
+                        const long long tiles = 36LL * ((Ts + bm - 1) / bm) * (L.cout_pad / bn);
+                        const long long pmax = 256LL * igemm_resident_blocks(gtile);
+                        gblocks = (int)(pmax > tiles ? tiles : pmax);
                     }
                     GemmStreamArgs g{};
                     g.A = c.winoV; g.W = L.wu; g.C = c.winoM; g.M = (int)Ts; g.K = L.cin_pad; g.Npad = L.cout_pad; g.nbatch = 36;
