@@ -97,3 +97,14 @@ def synth_pairs(n_pairs, h=112, w=112, seed=7, block=600):
             img2[i, :, h // 2:, :] = g.uniform(-1.0, 1.0, (3, h - h // 2, w))
     np.clip(img2, -1.0, 1.0, out=img2)
     return torch.from_numpy(img1), torch.from_numpy(img2), torch.from_numpy(labels)
+
+
+def synth_train_batch(n, seed=301, n_classes=10575):
+    """A synthetic training batch shaped like data/dataset.py's CASIA items (train.py:46-48):
+    clean images, the same images with a lower-right block replaced ('occluded'), identity labels."""
+    non = synth_images(n, 112, 112, seed=seed)
+    ocl = non.clone()
+    ocl[:, :, 56:, 40:] = synth_images(n, 112, 112, seed=seed + 1)[:, :, 56:, 40:]
+    g = np.random.Generator(np.random.Philox(key=(int(seed) << 32) | 0x1ABE1))
+    label = torch.from_numpy(g.integers(0, n_classes, n)).long()
+    return non, ocl, label

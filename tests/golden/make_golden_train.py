@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/g8_train_step.npz by running THE REFERENCE's own training-step code on CPU.
+
+Run in the build container only (needs /root/reference, which never travels):
+    python tests/golden/make_golden_train.py
+What runs is the reference's RecNet (train mode), AddMarginProduct head, Trainer.forward,
+Trainer.backward, clip_grad_value_ and torch.optim.Adam (models/trainer.py:139-187) on 4 seeded
+synthetic pairs with the synthetic weights of ffr-net_amd/synth.py.  Stored: the 7-tuple outputs,
+the four loss items, per-parameter gradient digests (sum, abs-sum, 64 strided samples), BN running
+statistics and parameter samples after one step.  Only outputs are stored, no reference source.
+
+Two accommodations, both outside the reference's files: the Trainer is built with object.__new__
+(its __init__ loads ./pretrain/se50.pth, which does not exist), and torch.zeros ignores the
+hard-coded device='cuda' of models/recnet.py:262 while the reference code runs (no GPU here).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import ffrnet_amd  # noqa: E402,F401
+from ffrnet_amd import synth  # noqa: E402
+from make_golden import import_reference, strided  # noqa: E402
+
+B = 4
+LR = 0.1            # run.py:12
+SEED = 301
+
+
+def digest(t, n=64):
+    t = t.detach()
+    return np.concatenate([[t.double().sum().item(), t.double().abs().sum().item()],
+                           strided(t, n).double().numpy()]).astype(np.float64)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _stub = types.ModuleType('utils_stub')  # noqa: F841
+    m_enc, m_rec, m_lfw = import_reference()
+    import models.trainer as m_tr
+
+    enc = m_enc.Backbone(num_layers=50, drop_ratio=0.6, mode='ir_se')
+    rec = m_rec.RecNet(channel=512, shape=7, norm_type='bn', relu_type='prelu')
+    spec_e = {k: list(v.shape) for k, v in enc.state_dict().items()}
+    spec_r = {k: list(v.shape) for k, v in rec.state_dict().items()}
+    enc.load_state_dict(synth.synth_state_dict(spec_e, seed=0))
+    rec.load_state_dict(synth.synth_state_dict(spec_r, seed=0))
+    for p in enc.parameters():
+        p.requires_grad = False
+
+    t = object.__new__(m_tr.Trainer)
+    t.opts = types.SimpleNamespace(optimizer='Adam', lr=LR, beta1=0.9, beta2=0.999, weight_decay=0,
+                                   momentum=0.9, loss_weight=[1, 1, 1, 1])
+    t.encoder, t.recnet = enc, rec
+    t.forward_encoder = lambda x: enc(x)
+    t.forward_recnet = lambda x, label: rec(x, label)
+    enc.eval()
+    rec.train()
+    t.config_optimizer()
+    t.config_criterion()
+
+    non, ocl, label = synth.synth_train_batch(B, seed=SEED)
+    t.set_input(non, ocl, label)
+    zeros = torch.zeros
+    torch.zeros = lambda *a, **k: zeros(*a, **{kk: vv for kk, vv in k.items() if kk != 'device'})
+    before = {k: v.detach().clone() for k, v in rec.state_dict().items()}
+    try:
+        t.forward()
+        out_non = [t.f_non, t.pred_loss_non, t.pred_label_non, t.M_space_non, t.M_channel_non, t.space_non,
+                   t.channel_non]
+        out_ocl = [t.f_ocl, t.pred_loss_ocl, t.pred_label_ocl, t.M_space_ocl, t.M_channel_ocl, t.space_ocl,
+                   t.channel_ocl]
+        t.optimizer_parameters(1)
+    finally:
+        torch.zeros = zeros
+    g8 = dict(B=np.int64(B), lr=np.float64(LR), label=label.numpy(),
+              input_checksum=np.float64(non.double().sum().item() + ocl.double().sum().item()),
+              losses=np.array([float(l.detach()) for l in t.loss_items], dtype=np.float64),
+              accuracy=np.float64(t.accuracy))
+    names = ['f', 'pred_loss', 'pred_label', 'M_space', 'M_channel', 'feat_space', 'feat_channel']
+    for tag, outs in (('non', out_non), ('ocl', out_ocl)):
+        for nm, o in zip(names, outs):
+            g8['out.%s.%s' % (tag, nm)] = digest(o, 256)
+        g8['full.%s.f' % tag] = outs[0].detach().numpy()
+        g8['full.%s.M_space0' % tag] = outs[3][0].detach().numpy()
+        g8['full.%s.feat_channel0' % tag] = outs[6][0].detach().numpy()
+    after = rec.state_dict()
+    for k, p in rec.named_parameters():
+        g8['grad.' + k] = digest(p.grad)            # after clip_grad_value_(1.0)
+        g8['after.' + k] = digest(after[k])
+    for k in after:
+        if k.endswith(('running_mean', 'running_var')):
+            g8['after.' + k] = after[k].numpy().astype(np.float64)
+        if k.endswith('num_batches_tracked'):
+            assert int(after[k]) == int(before[k]) + 2
+    np.savez_compressed(os.path.join(HERE, 'g8_train_step.npz'), **g8)
+    print('losses', g8['losses'], 'acc', g8['accuracy'])
+    print('g8_train_step.npz', os.path.getsize(os.path.join(HERE, 'g8_train_step.npz')), 'B')
+
+    # ---- the oracle against the reference, right here -------------------------------------
+    import ffr_oracle_train as OT
+    sd_e = synth.synth_state_dict(spec_e, seed=0)
+    sd_r = synth.synth_state_dict(spec_r, seed=0)
+    opt = OT.new_adam_state(sd_r)
+    res = OT.train_step(sd_e, sd_r, opt, non, ocl, label, lr=LR)
+    print('oracle losses', res['losses'])
+    worst = 0.0
+    for k, p in rec.named_parameters():
+        a, b = p.grad, res['grads'][k]
+        e = (a - b).abs().max().item() / (a.abs().max().item() + 1e-30)
+        worst = max(worst, e)
+    print('worst grad rel err (oracle vs reference): %.3g' % worst)
+
+
+if __name__ == '__main__':
+    main()
