@@ -6,76 +6,15 @@
 //   bottleneck_IR_SE / SEModule pretrain/model_ir_se50.py:18-36,56-76
 //   RecNet.forward (label=None) models/recnet.py:398-426
 //   calculate_distance cosine   lfw/lfw_eval.py:246,248
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/ffrnet.h"
-#include "ffr_kernels.h"
+#include "engine_internal.h"
 
 using namespace ffr;
+using namespace ffr_eng;
 
-namespace {
+namespace ffr_eng {
 
 const double BN_EPS = 1e-5;
 std::string g_err = "";
-
-struct ConvW {
-    int cin = 0, cin_pad = 0, cout = 0, cout_pad = 0, R = 1, S = 1, stride = 1, pad = 0, pad_mode = 0, border = 0;
-    float* w = nullptr;
-    float* bias = nullptr;
-    float* slope = nullptr;
-    float* wu = nullptr;     // Winograd F(4,3) weights [36][cout_pad][cin_pad] (G g G^T, BN folded) or null
-};
-
-struct Block {
-    int cin = 0, depth = 0, stride = 1;
-    bool has_sc = false;
-    ConvW c1, c2, sc;
-    float* fc1 = nullptr;
-    float* fc2 = nullptr;
-};
-
-struct ProfRec {
-    hipEvent_t e0, e1;
-    int kc;
-    double flops, bytes, fexec;
-};
-
-}  // namespace
-
-struct ffr_handle {
-    int device = 0;
-    std::string err;
-    float* zero = nullptr;   // 128 KiB zero page (source of zero-padded taps, >= any cin_pad)
-    // weights
-    std::vector<void*> enc_allocs, rec_allocs;
-    bool enc_loaded = false, rec_loaded = false;
-    float *stem_w = nullptr, *stem_b = nullptr, *stem_s = nullptr;
-    Block blocks[24];
-    float *bn_s = nullptr, *bn_t = nullptr;
-    ConvW fc;
-    ConvW sp[9], fm[3], mg[3];
-    ChannelPathWeights cw{};
-    // workspace arena
-    char* arena = nullptr;
-    size_t arena_bytes = 0;
-    int* tickets = nullptr;      // stream-K arrival counters (zero between launches)
-    size_t tickets_cap = 0;
-    // profiling
-    bool prof = false;
-    std::vector<ProfRec> prof_log;
-    std::vector<hipEvent_t> ev_pool;
-};
-
-namespace {
 
 int fail(ffr_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -87,64 +26,9 @@ int fail(ffr_handle* h, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIPCK(h, expr)                                                                          \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess)                                                                   \
-            return fail(h, FFR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-
-#define RC(expr)                  \
-    do {                          \
-        int _rc = (expr);         \
-        if (_rc != FFR_OK) return _rc; \
-    } while (0)
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-// ---- profiling scope: hipEvents on the launch stream around one launch -----------------
-struct Scope {
-    ffr_handle* h;
-    hipStream_t st;
-    ProfRec r;
-    bool on;
-    Scope(ffr_handle* h_, hipStream_t st_, int kc, double flops, double bytes, double fexec = -1.0)
-        : h(h_), st(st_), on(h_->prof) {
-        if (!on) return;
-        auto get = [&]() {
-            hipEvent_t e;
-            if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); }
-            else hipEventCreate(&e);
-            return e;
-        };
-        r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes; r.fexec = fexec < 0 ? flops : fexec;
-        hipEventRecord(r.e0, st);
-    }
-    ~Scope() {
-        if (!on) return;
-        hipEventRecord(r.e1, st);
-        h->prof_log.push_back(r);
-    }
-};
 
 // ---- host-side state_dict access -----------------------------------------------------------
-struct SD {
-    std::map<std::string, const ffr_tensor_desc*> m;
-    ffr_handle* h;
-    int rc = FFR_OK;
-    const float* get(const std::string& name, std::initializer_list<int64_t> shape) {
-        auto it = m.find(name);
-        if (it == m.end()) { rc = fail(h, FFR_ERR_KEY, "state_dict entry '%s' is missing", name.c_str()); return nullptr; }
-        const ffr_tensor_desc* d = it->second;
-        bool ok = d->data && d->ndim == (int)shape.size();
-        int i = 0;
-        for (int64_t s : shape) { if (ok && d->shape[i] != s) ok = false; ++i; }
-        if (!ok) { rc = fail(h, FFR_ERR_KEY, "state_dict entry '%s' has an unexpected shape", name.c_str()); return nullptr; }
-        return d->data;
-    }
-};
 
-struct BNFold { std::vector<double> s, t; };
 bool bn_fold(SD& sd, const std::string& p, int C, BNFold& o) {
     const float* g = sd.get(p + ".weight", {C});
     const float* b = sd.get(p + ".bias", {C});
@@ -322,16 +206,6 @@ void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, i
     *nblocks = (int)p;
 }
 
-struct ConvCall {
-    const float* x; int N, H, W, in_pitch;
-    const float* resid; int res_pitch;
-    float* out; int out_pitch, out_coff, cout_store;
-    int flags; int tile; int splitk;      // splitk: ignored (stream-K balances K itself)
-    float* partial; size_t partial_cap;   // floats
-    int* tickets; size_t tickets_cap;
-    float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
-    int wino_mode = -1;                            // -1 auto (env FFR_WINO), 0 never, 1 whenever packed
-};
 
 // plan + launch one (possibly batched) implicit-GEMM described by `a` (M, nkt, cout_pad, nbatch set)
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st) {
@@ -488,28 +362,6 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
 }
 
 // ---- workspace ---------------------------------------------------------------------------
-struct Arena {
-    char* base; size_t off = 0, cap;
-    Arena(char* b, size_t c) : base(b), cap(c) {}
-    float* take(size_t floats) {
-        size_t bytes = (floats * 4 + 255) & ~(size_t)255;
-        float* p = base ? (float*)(base + off) : nullptr;
-        off += bytes;
-        return p;
-    }
-};
-
-struct Work {
-    // encoder
-    float *bufA, *bufB, *t1, *res, *sc, *scale, *se_part, *trunk_bn;
-    // shared
-    float* partial; size_t partial_cap;
-    int* tickets; size_t tickets_cap;
-    float *winoV, *winoM; size_t wino_cap;
-    // recnet
-    float *X, *bufS, *bufF, *bufM, *s256a, *s256b, *s256c, *ms, *m512a, *m512b, *m512c, *dbg;
-    size_t total;
-};
 
 Work layout(char* base, int N, int H, int W) {
     Arena a(base, 0);
@@ -582,7 +434,6 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
 
 // ---- encoder ---------------------------------------------------------------------------
 // Runs stem + n_blocks bottlenecks; *out_ptr = NHWC result, *oh/*ow/*oc its geometry.
-struct U8In { const unsigned char* img; const unsigned char* flip; };
 
 int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, int W, int n_blocks, hipStream_t st,
               float** out_ptr, int* oh, int* ow, int* oc, const U8In* u8 = nullptr) {
@@ -635,7 +486,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
 
 // trunk -> featmap (NHWC in w.X / w.trunk_bn) and f
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
-                hipStream_t st, const U8In* u8 = nullptr) {
+                hipStream_t st, const U8In* u8) {
     float* t; int oh, ow, oc;
     RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc, u8));
     const int P = oh * ow;
@@ -657,7 +508,6 @@ int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int 
 }
 
 // ---- recnet ----------------------------------------------------------------------------
-struct RecDebug { float *ss_space, *M_space, *feat_space, *feat_channel_raw, *feat_channel; };
 
 int conv_rec(ffr_handle* h, const Work& w, const ConvW& L, const float* x, int in_pitch, const float* resid,
              int res_pitch, float* out, int out_pitch, int out_coff, int flags, int N, hipStream_t st) {
@@ -737,7 +587,7 @@ int check_fwd(ffr_handle* h, bool need_enc, bool need_rec, int N) {
     return FFR_OK;
 }
 
-}  // namespace
+}  // namespace ffr_eng
 
 // =========================================================================================
 extern "C" {
@@ -779,6 +629,7 @@ void ffr_destroy(ffr_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     hipDeviceSynchronize();
+    train_free(h);
     free_list(h->enc_allocs);
     free_list(h->rec_allocs);
     if (h->arena) hipFree(h->arena);

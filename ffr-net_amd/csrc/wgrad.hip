@@ -1,0 +1,201 @@
+// Weight-gradient GEMM of the RecNet training step on the fp32 matrix cores:
+//
+//     dW[co][j] = sum_m dy[m][co] * xg[m][j]        j = (tap, ci),  m = (img, h, w)
+//
+// (torch's conv2d backward wrt the weight for ConvLayer, reference models/recnet.py:52-85, and the
+// plain  dW = dY^T X  of the nn.Linear layers, with taps = 1).  Both operands are "K-major" in
+// memory -- the reduction index m is the row index of dy[rows][cout] and of the NHWC activation --
+// so this is a TN GEMM.  LDS-DMA cannot transpose, hence the LDS image stays K-major ([32 k][128]
+// per operand and stage) and fragments are read with ds_read_b32 (lane = (column, k parity)): 4 reads
+// per 4 MFMAs and wave, conflict-free through an XOR of column bit 5 with the k parity applied on the
+// SOURCE side of the DMA.  xg is gathered on the fly: reflect padding 1 (pad_mode 1, ConvLayer) or
+// zero padding resolved per 16-byte piece; columns beyond taps*cin_pad and rows beyond `rows` come
+// from the zero page.
+//
+// Split-K: the row range is cut into `splits` slabs out[split][cout_pad][Ng]; k_wgrad_reduce adds the
+// slabs in a fixed order (bitwise reproducible) and accumulates into / overwrites the gradient.
+#include "train_kernels.h"
+
+namespace ffr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// BM x 128 output tile, BK = 32 rows per K-tile, 4 waves as 2 x 2
+template <int BM>
+__global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
+    constexpr int BN = 128;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_INSTR = BM / 32;              // DMA instructions per wave and K-tile for the dy tile
+    constexpr int B_INSTR = BN / 32;
+    constexpr int STAGE = 32 * (BM + BN);
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int par = lane >> 5;                    // k parity this lane stages and reads
+
+    int bid = blockIdx.x;
+    const int nt = bid % a.ntiles; bid /= a.ntiles;
+    const int mt = bid % a.mtiles; bid /= a.mtiles;
+    const int split = bid;
+    const int co0 = mt * BM, n0 = nt * BN;
+    const int kt0 = split * a.kt_per_split;
+    int kt1 = kt0 + a.kt_per_split;
+    if (kt1 > a.nkt) kt1 = a.nkt;
+
+    // this lane's 16-byte piece inside a staged row: position cpos, logical column chunk cl
+    const int cposA = lane & (BM / 4 - 1);        // BM/4 pieces per row
+    const int cpos = lane & 31;
+    const int clA = cposA ^ (((lane / (BM / 4)) & 1) << 3);   // parity of the row this lane stages
+    const int cl = cpos ^ (par << 3);
+    // B column -> (tap, ci)
+    const int j = n0 + cl * 4;
+    const bool jok = j < a.Ng;
+    const int tap = jok ? j / a.cin_pad : 0;
+    const int ci = jok ? j - tap * a.cin_pad : 0;
+    const int dr = tap / 3 - (a.taps == 9 ? 1 : 0), ds = tap % 3 - (a.taps == 9 ? 1 : 0);
+    const int HW = a.H * a.W;
+
+    auto stage_tile = [&](int buf, int kt) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + 32 * BM;
+        const int m0 = kt * 32;
+        // dy tile: rows of BM floats; an instruction covers 64 pieces = 256 floats
+#pragma unroll
+        for (int q = 0; q < A_INSTR; ++q) {
+            const int piece = (q * 4 + wave) * 64;              // first piece of this instruction
+            const int k = (piece + lane) / (BM / 4);
+            const int m = m0 + k;
+            const float* src = (m < a.rows) ? a.dy + (size_t)m * a.dy_pitch + co0 + clA * 4 : a.zero;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + piece * 4), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_INSTR; ++q) {
+            const int piece = (q * 4 + wave) * 64;
+            const int k = (piece + lane) >> 5;
+            const int m = m0 + k;
+            const float* src = a.zero;
+            if (jok && m < a.rows) {
+                const int img = m / HW;
+                const int p = m - img * HW;
+                int h = p / a.W;
+                int w = p - h * a.W;
+                h += dr; w += ds;
+                bool ok = true;
+                if (a.pad_mode == 1) {
+                    h = h < 0 ? -h : (h >= a.H ? 2 * a.H - 2 - h : h);
+                    w = w < 0 ? -w : (w >= a.W ? 2 * a.W - 2 - w : w);
+                } else {
+                    ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+                }
+                if (ok) src = a.x + ((size_t)img * HW + h * a.W + w) * a.x_pitch + ci;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sB + piece * 4), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+    // fragment columns (swizzled by this lane's k parity)
+    int colA[TM], colB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) colA[i] = (wm * WM + i * 32 + (lane & 31)) ^ (par << 5);
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) colB[jj] = (wn * WN + jj * 32 + (lane & 31)) ^ (par << 5);
+
+    if (kt0 < kt1) {
+        stage_tile(0, kt0);
+        int cur = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < kt1) stage_tile(cur ^ 1, kt + 1);
+            const float* sA = smem + cur * STAGE;
+            const float* sB = sA + 32 * BM;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int k = kk * 2 + par;
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = sA[k * BM + colA[i]];
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) bv[jj] = sB[k * BN + colB[jj]];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jj], acc[i][jj], 0, 0, 0);
+            }
+            cur ^= 1;
+        }
+    }
+    // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* out = a.out + (size_t)split * a.cout_pad * a.Ng;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {
+            const int col = n0 + wn * WN + jj * 32 + (lane & 31);
+            if (col < a.Ng) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = co0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * par;
+                    out[(size_t)row * a.Ng + col] = acc[i][jj][r];
+                }
+            }
+        }
+}
+
+// grad[i] (+)= scale * sum_s slabs[s][i]
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ grad,
+                                                     long long n4, int splits, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
+    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
+    if (accumulate) s += reinterpret_cast<const f32x4*>(grad)[i];
+    reinterpret_cast<f32x4*>(grad)[i] = s;
+}
+
+hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch, size_t scratch_floats,
+                        hipStream_t stream) {
+    if (a.cout_pad % 64 || a.cin_pad % 4 || (a.taps != 1 && a.taps != 9) || a.rows <= 0) return hipErrorInvalidValue;
+    a.Ng = a.taps * a.cin_pad;
+    if (a.Ng % 4) return hipErrorInvalidValue;
+    const int bm = (a.cout_pad % 128 == 0) ? 128 : 64;
+    a.mtiles = a.cout_pad / bm;
+    a.ntiles = (a.Ng + 127) / 128;
+    a.nkt = (a.rows + 31) / 32;
+    // enough blocks for two rounds over the chip, at least 8 K-tiles per split
+    const long long tiles = (long long)a.mtiles * a.ntiles;
+    int splits = (int)((2 * 512 + tiles - 1) / tiles);
+    if (splits > a.nkt / 8) splits = a.nkt / 8;
+    if (splits < 1) splits = 1;
+    const size_t per = (size_t)a.cout_pad * a.Ng;
+    while (splits > 1 && (size_t)splits * per > scratch_floats) --splits;
+    if (per > scratch_floats) return hipErrorOutOfMemory;
+    a.kt_per_split = (a.nkt + splits - 1) / splits;
+    splits = (a.nkt + a.kt_per_split - 1) / a.kt_per_split;
+    a.splits = splits;
+    a.out = scratch;
+    const unsigned grid = (unsigned)(tiles * splits);
+    if (bm == 128) hipLaunchKernelGGL(k_wgrad<128>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(k_wgrad<64>, dim3(grid), dim3(256), 0, stream, a);
+    const long long n4 = (long long)per / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, grad, n4, splits,
+                       accumulate);
+    return hipGetLastError();
+}
+
+}  // namespace ffr

@@ -68,6 +68,8 @@ SYMBOLS = [
     ('ffr_op_conv3x3', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ('ffr_encoder_trunk_nhwc', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     ('ffr_recnet_debug', C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    # include/ffrnet_train.h
+    ('ffr_op_convlayer_train', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 ]
 
 
@@ -311,6 +313,38 @@ class Engine(object):
                                              _ptr(resid.contiguous()) if resid is not None else C.c_void_p(0),
                                              _ptr(out), self._stream()))
         return out
+
+    def op_convlayer_train(self, x_nhwc, G, w, gamma, beta, slope, da_nhwc, need_dx=True):
+        """One ConvLayer in train() mode (models/recnet.py:78-85), forward + backward (test hook).
+        x_nhwc [G*N,7,7,cin] and da_nhwc [G*N,7,7,cout] device tensors (logical channel counts);
+        w [cout,cin,3,3], gamma/beta/slope [cout] host tensors.
+        Returns dict(out, dx, dw[cout,cin,3,3], dgamma, dbeta, dslope, running_mean, running_var, mean, invstd)."""
+        _check_dev(x_nhwc, 'x')
+        gn, hh, ww, cin = x_nhwc.shape
+        assert hh == 7 and ww == 7 and gn % G == 0
+        cout = w.size(0)
+        cin_pad, cout_pad = (cin + 31) // 32 * 32, (cout + 63) // 64 * 64
+        rows = gn * 49
+        dev = x_nhwc.device
+        xp = torch.zeros((rows, cin_pad), device=dev)
+        xp[:, :cin] = x_nhwc.reshape(rows, cin)
+        dap = torch.zeros((rows, cout_pad), device=dev)
+        dap[:, :cout] = da_nhwc.reshape(rows, cout)
+        host = [t.detach().float().cpu().contiguous() for t in (w, gamma, beta, slope)]
+        out = torch.empty((rows, cout_pad), device=dev)
+        dx = torch.zeros((rows, cin_pad), device=dev) if need_dx else None
+        dw = torch.empty((cout_pad, 9, cin_pad), device=dev)
+        dvec = torch.empty((5, cout_pad), device=dev)
+        stats = torch.empty((2, G, cout_pad), device=dev)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_op_convlayer_train(self._h, _ptr(xp), G, gn // G, cin, cout,
+                                                     *[C.c_void_p(t.data_ptr()) for t in host], _ptr(dap), _ptr(out),
+                                                     _ptr(dx), _ptr(dw), _ptr(dvec), _ptr(stats), self._stream()))
+        dwt = dw[:cout, :, :cin].reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+        return dict(out=out[:, :cout].reshape(gn, 7, 7, cout), dx=dx[:, :cin].reshape(gn, 7, 7, cin) if need_dx else None,
+                    dw=dwt, dgamma=dvec[0, :cout], dbeta=dvec[1, :cout], dslope=dvec[2, :cout],
+                    running_mean=dvec[3, :cout], running_var=dvec[4, :cout], mean=stats[0, :, :cout],
+                    invstd=stats[1, :, :cout])
 
     def encoder_trunk_nhwc(self, x, n_blocks):
         _check_dev(x, 'x')

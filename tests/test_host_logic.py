@@ -63,11 +63,12 @@ def test_no_cpu_fallback():
 
 
 def test_c_abi_exports_every_declared_symbol():
-    """The .so loads without a GPU and exports each function include/ffrnet.h declares."""
+    """The .so loads without a GPU and exports each function include/*.h declares."""
     path = native.lib_path()
     assert os.path.exists(path), 'run __graft_entry__.build() first'
     lib = ctypes.CDLL(path)
-    hdr = open(os.path.join(ROOT, 'include', 'ffrnet.h')).read()
+    import glob
+    hdr = ''.join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, 'include', '*.h'))))
     declared = set(re.findall(r'\b(ffr_[a-z_0-9]+)\s*\(', hdr))
     bound = {n for n, _, _ in native.SYMBOLS}
     assert declared == bound, (declared ^ bound)
