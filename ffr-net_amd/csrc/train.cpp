@@ -124,14 +124,370 @@ std::vector<float> pack3x3(const float* W, int cout, int cin, int cout_pad, int 
     return p;
 }
 
+
+// ---- plain GEMMs through the implicit-GEMM kernel ---------------------------------------------------
+// out[rows][N_pad] = A[rows][K_pad] * W[N_pad][K_pad]^T + bias (+ resid) (sigmoid when flags & 1)
+int gemm_rows(ffr_handle* h, const Work& w, const float* A, int a_pitch, int K_pad, const float* W, const float* bias,
+              int N_pad, float* out, int out_pitch, long long rows, const float* resid, int res_pitch, int flags,
+              hipStream_t st) {
+    ConvW cw;
+    cw.cin = K_pad; cw.cin_pad = K_pad; cw.cout = N_pad; cw.cout_pad = N_pad; cw.R = 1; cw.S = 1; cw.stride = 1; cw.pad = 0;
+    cw.pad_mode = 0; cw.border = 0; cw.w = const_cast<float*>(W); cw.bias = bias ? const_cast<float*>(bias) : h->zero;
+    cw.slope = nullptr; cw.wu = nullptr;
+    ConvCall c{};
+    c.x = A; c.N = 1; c.H = 1; c.W = (int)rows; c.in_pitch = a_pitch; c.resid = resid; c.res_pitch = res_pitch;
+    c.out = out; c.out_pitch = out_pitch; c.out_coff = 0; c.cout_store = N_pad; c.flags = flags;
+    conv_call_common(c, w);
+    return run_conv(h, cw, c, st);
+}
+
+// nbatch independent GEMMs out[b][M][out_pitch] = A[b][M][K_pad] * W[b][N_pad][K_pad]^T
+int gemm_batched(ffr_handle* h, const Work& w, const float* A, long long a_bstride, int K_pad, const float* W,
+                 long long w_bstride, int N_pad, float* out, int out_pitch, long long out_bstride, int M, int nbatch,
+                 hipStream_t st) {
+    IgemmArgs g{};
+    g.x = A; g.w = W; g.bias = h->zero; g.slope = nullptr; g.resid = nullptr; g.out = out; g.zero = h->zero;
+    g.N = 1; g.H = 1; g.W = M; g.Ho = 1; g.Wo = M;
+    g.in_pitch = K_pad; g.cin_pad = K_pad; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.pad_mode = 0;
+    g.M = M; g.KK = K_pad; g.nkt = K_pad / 32;
+    g.cout_pad = N_pad; g.cout_store = N_pad; g.out_pitch = out_pitch; g.out_coff = 0; g.res_pitch = 0;
+    g.border_bias = 0; g.flags = 0;
+    g.nbatch = nbatch; g.x_bstride = a_bstride; g.w_bstride = w_bstride; g.out_bstride = out_bstride;
+    ConvCall c{};
+    conv_call_common(c, w);
+    const double fl = 2.0 * nbatch * (double)M * N_pad * K_pad;
+    return run_gemm(h, g, c, fl, 4.0 * nbatch * ((double)M * K_pad + (double)N_pad * K_pad + (double)M * N_pad), st);
+}
+
+enum SegKind { SEG_CONV, SEG_VEC, SEG_LIN };
+struct Seg {
+    std::string key;
+    SegKind kind;
+    size_t off = 0, n_native = 0, n_natural = 0;
+    int d0 = 0, d1 = 0, p0 = 0, p1 = 0;     // natural dims (cout,cin | n,1 | out,in) and their padded sizes
+    int colperm = 0;                        // Linear(561,32): native columns = [ss_channel (512) | X (49) | pad]
+    size_t native_index(size_t i) const {
+        if (kind == SEG_VEC) return i;
+        if (kind == SEG_CONV) {
+            const size_t t = i % 9, ci = (i / 9) % d1, co = i / 9 / d1;
+            return (co * 9 + t) * p1 + ci;
+        }
+        const size_t in = i % d1, o = i / d1;
+        const size_t col = colperm ? (in < 49 ? 512 + in : in - 49) : in;
+        return o * p1 + col;
+    }
+};
+
+struct Lin {
+    int in = 0, out = 0, in_pad = 0, out_pad = 0;
+    float *w = nullptr, *b = nullptr, *gw = nullptr, *gb = nullptr;
+};
+
+const int N_CLASSES = 10575, CLS_PAD = 10624;
+const float COSFACE_S = 30.0f, COSFACE_M = 0.40f;
+
+// activations one forward call keeps for its backward
+struct Ctx {
+    int G = 0, N = 0;
+    void* mem = nullptr;
+    float *X, *bufS, *bufF, *bufM, *ms, *featnew;
+    TSaved sp[9], fm[3], mg[3];
+    float* out_sp[9]; float* out_fm[2]; float* out_mg[2];
+    float *Xt, *Xht, *cat, *h1pre, *h1, *t2, *h2pre, *h2, *t5, *h3pre, *h3, *Mc, *raw;
+    float *fnew, *fn, *fnorm, *cosv, *wn, *wnorm;
+    int* label;
+    bool valid = false;
+};
+
 }  // namespace
 
 struct TrainState {
     std::vector<void*> allocs;
+    std::vector<Seg> segs;
+    std::map<std::string, int> seg_of;
+    std::map<std::string, std::pair<float*, int>> running_of;     // key -> (device ptr, n)
+    size_t n_flat = 0;
+    float *P = nullptr, *Gr = nullptr, *M1 = nullptr, *M2 = nullptr, *running = nullptr;
+    long long nbt = 0;             // BatchNorm updates since ffr_train_init (num_batches_tracked increments)
+    TLayer sp[9], fm[3], mg[3];
+    Lin lin[6];
+    float *a[3] = {nullptr, nullptr, nullptr}, *ga[3] = {nullptr, nullptr, nullptr};
+    float *clsW = nullptr, *gclsW = nullptr;
+    int adam_step = 0;
+    Ctx ctx[2];
+    // backward scratch, sized for `scratch_imgs`
+    int scratch_imgs = 0;
+    void* scratch_mem = nullptr;
+    TScratch sc;
+    float *dFeatNew, *d512a, *d512b, *dBufM, *extM, *dF, *d256a, *d256b, *d256c, *dms;
+    float *dRawt, *dMc, *dt, *d32a, *d32b, *rowdot, *dcos, *dfn, *df, *dwn, *wnT, *wT;
 };
+
+namespace {
+
+struct LayerDef { const char* p; int cin, cout; };
+const LayerDef SP_DEF[9] = {{"Conv4Space.0", 561, 256}, {"Conv4Space.1.conv1", 256, 256}, {"Conv4Space.1.conv2", 256, 256},
+                            {"Conv4Space.2", 256, 128}, {"Conv4Space.3.conv1", 128, 128}, {"Conv4Space.3.conv2", 128, 128},
+                            {"Conv4Space.4", 128, 49}, {"Conv4Space.5.conv1", 49, 49}, {"Conv4Space.5.conv2", 49, 49}};
+const LayerDef FM_DEF[3] = {{"ChannelFlipMerge.0", 1024, 512}, {"ChannelFlipMerge.1.conv1", 512, 512},
+                            {"ChannelFlipMerge.1.conv2", 512, 512}};
+const LayerDef MG_DEF[3] = {{"Conv4Merge.0", 1536, 512}, {"Conv4Merge.1.conv1", 512, 512}, {"Conv4Merge.1.conv2", 512, 512}};
+const int LIN_IDX[6] = {0, 2, 3, 5, 6, 8};
+const int LIN_IN[6] = {561, 32, 512, 32, 512, 32}, LIN_OUT[6] = {32, 512, 32, 512, 32, 512};
+const int ACT_IDX[3] = {1, 4, 7};
+
+size_t add_seg(TrainState* t, const std::string& key, SegKind kind, int d0, int d1, int p0, int p1, int colperm = 0) {
+    Seg s;
+    s.key = key; s.kind = kind; s.d0 = d0; s.d1 = d1; s.p0 = p0; s.p1 = p1; s.colperm = colperm;
+    s.n_natural = kind == SEG_CONV ? (size_t)d0 * d1 * 9 : (size_t)d0 * d1;
+    s.n_native = kind == SEG_CONV ? (size_t)p0 * 9 * p1 : (size_t)p0 * p1;
+    s.off = t->n_flat;
+    t->n_flat += (s.n_native + 63) / 64 * 64;
+    t->seg_of[key] = (int)t->segs.size();
+    t->segs.push_back(s);
+    return s.off;
+}
+
+void free_ctx(Ctx& c) {
+    if (c.mem) hipFree(c.mem);
+    c = Ctx();
+}
+
+int ensure_ctx(ffr_handle* h, TrainState* t, Ctx& c, int G, int N) {
+    if (c.mem && c.G == G && c.N == N) return FFR_OK;
+    hipDeviceSynchronize();
+    free_ctx(c);
+    const size_t imgs = (size_t)G * N, rows = imgs * 49, crow = imgs * 512;
+    auto carve = [&](char* base) -> size_t {
+        Arena a(base, 0);
+        c.X = a.take(rows * 512 + 64 * 512);
+        c.bufS = a.take(rows * 576); c.bufF = a.take(rows * 1024); c.bufM = a.take(rows * 1536);
+        c.ms = a.take(rows * 64); c.featnew = a.take(rows * 512);
+        auto layer = [&](const TLayer& L, TSaved& sv) {
+            sv.y = a.take(rows * L.cout_pad);
+            float* p = a.take((size_t)6 * G * L.cout_pad);
+            const size_t gc = (size_t)G * L.cout_pad;
+            sv.bn.mean = p; sv.bn.invstd = p ? p + gc : nullptr; sv.bn.scale = p ? p + 2 * gc : nullptr;
+            sv.bn.shift = p ? p + 3 * gc : nullptr; sv.bn.c1 = p ? p + 4 * gc : nullptr; sv.bn.c2 = p ? p + 5 * gc : nullptr;
+        };
+        for (int i = 0; i < 9; ++i) { layer(t->sp[i], c.sp[i]); c.out_sp[i] = a.take(rows * t->sp[i].cout_pad); }
+        for (int i = 0; i < 3; ++i) layer(t->fm[i], c.fm[i]);
+        for (int i = 0; i < 3; ++i) layer(t->mg[i], c.mg[i]);
+        for (int i = 0; i < 2; ++i) { c.out_fm[i] = a.take(rows * 512); c.out_mg[i] = a.take(rows * 512); }
+        c.Xt = a.take(crow * 64); c.Xht = a.take(crow * 64); c.cat = a.take(crow * 576);
+        c.h1pre = a.take(crow * 64); c.h1 = a.take(crow * 64); c.t2 = a.take(crow * 512);
+        c.h2pre = a.take(crow * 64); c.h2 = a.take(crow * 64); c.t5 = a.take(crow * 512);
+        c.h3pre = a.take(crow * 64); c.h3 = a.take(crow * 64); c.Mc = a.take(crow * 512); c.raw = a.take(crow * 64);
+        c.fnew = a.take(imgs * 512); c.fn = a.take(imgs * 512); c.fnorm = a.take(imgs + 64);
+        c.cosv = a.take(imgs * CLS_PAD); c.wn = a.take((size_t)CLS_PAD * 512); c.wnorm = a.take(CLS_PAD);
+        c.label = (int*)a.take(imgs + 64);
+        return a.off;
+    };
+    const size_t need = carve(nullptr);
+    if (hipMalloc(&c.mem, need) != hipSuccess) { c.mem = nullptr; return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu training-context bytes failed", need); }
+    carve((char*)c.mem);
+    HIPCK(h, hipMemset(c.mem, 0, need));
+    c.G = G; c.N = N;
+    return FFR_OK;
+}
+
+int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
+    if (t->scratch_mem && t->scratch_imgs >= imgs_i) return FFR_OK;
+    hipDeviceSynchronize();
+    if (t->scratch_mem) hipFree(t->scratch_mem);
+    t->scratch_mem = nullptr;
+    const size_t imgs = imgs_i, rows = imgs * 49, crow = imgs * 512;
+    auto carve = [&](char* base) -> size_t {
+        Arena a(base, 0);
+        size_t partd = bn_part_doubles(1, (int)(rows > crow ? rows : crow), 1536);
+        t->sc.part = (double*)a.take(partd * 2);
+        t->sc.wd_floats = (size_t)1536 * 9 * 512; t->sc.wd = a.take(t->sc.wd_floats);
+        t->sc.dxp_floats = imgs * 81 * 1024; t->sc.dxp = a.take(t->sc.dxp_floats);
+        t->sc.dy_floats = rows * 512; t->sc.dy = a.take(t->sc.dy_floats);
+        t->sc.slab_floats = (size_t)4 * 512 * 9 * 1536; t->sc.slabs = a.take(t->sc.slab_floats);
+        t->dFeatNew = a.take(rows * 512); t->d512a = a.take(rows * 512); t->d512b = a.take(rows * 512);
+        t->dBufM = a.take(rows * 1024); t->extM = a.take(rows * 1024); t->dF = a.take(rows * 1024);
+        t->d256a = a.take(rows * 256); t->d256b = a.take(rows * 256); t->d256c = a.take(rows * 256); t->dms = a.take(rows * 64);
+        t->dRawt = a.take(crow * 64); t->dMc = a.take(crow * 512); t->dt = a.take(crow * 512);
+        t->d32a = a.take(crow * 64); t->d32b = a.take(crow * 64); t->rowdot = a.take(crow);
+        t->dcos = a.take(imgs * CLS_PAD); t->dfn = a.take(imgs * 512); t->df = a.take(imgs * 512);
+        t->dwn = a.take((size_t)CLS_PAD * 512); t->wnT = a.take((size_t)512 * CLS_PAD); t->wT = a.take((size_t)512 * 576);
+        return a.off;
+    };
+    const size_t need = carve(nullptr);
+    if (hipMalloc(&t->scratch_mem, need) != hipSuccess) { t->scratch_mem = nullptr; return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu training-scratch bytes failed", need); }
+    carve((char*)t->scratch_mem);
+    HIPCK(h, hipMemset(t->scratch_mem, 0, need));
+    t->scratch_imgs = imgs_i;
+    return FFR_OK;
+}
+
+int get_train(ffr_handle* h, TrainState** t) {
+    if (!h) return fail(nullptr, FFR_ERR_ARG, "null handle");
+    if (!h->train) return fail(h, FFR_ERR_STATE, "ffr_train_init has not been called");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    *t = h->train;
+    return FFR_OK;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------
+int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream_t st) {
+    const int G = c.G, N = c.N, imgs = G * N, rows = imgs * 49;
+    const long long crow = (long long)imgs * 512;
+    double* part = t->sc.part;
+    HIPCK(h, launch_copy_slice(c.X, c.bufS, rows, 512, 576, 0, st));
+    HIPCK(h, launch_copy_slice(c.X, c.bufM, rows, 512, 1536, 1024, st));
+    HIPCK(h, launch_selfsim_space(c.X, c.bufS, 576, nullptr, imgs, st));
+    t->nbt += G;      // num_batches_tracked: every BatchNorm of the net sees G batches per call
+    auto L = [&](const TLayer& Ly, TSaved& sv, const float* x, int x_pitch, const float* resid, int res_pitch, float* out,
+                 int out_pitch, int out_coff, int flags) -> int {
+        sv.x = x; sv.x_pitch = x_pitch;
+        return layer_forward(h, w, Ly, sv, G, N, resid, res_pitch, out, out_pitch, out_coff, flags, true, part, st);
+    };
+    // Conv4Space (recnet.py:362-371) -> M_space (pitch-64 rows, sigmoid)
+    RC(L(t->sp[0], c.sp[0], c.bufS, 576, nullptr, 0, c.out_sp[0], 256, 0, 0));
+    RC(L(t->sp[1], c.sp[1], c.out_sp[0], 256, nullptr, 0, c.out_sp[1], 256, 0, 0));
+    RC(L(t->sp[2], c.sp[2], c.out_sp[1], 256, c.out_sp[0], 256, c.out_sp[2], 256, 0, 0));
+    RC(L(t->sp[3], c.sp[3], c.out_sp[2], 256, nullptr, 0, c.out_sp[3], 128, 0, 0));
+    RC(L(t->sp[4], c.sp[4], c.out_sp[3], 128, nullptr, 0, c.out_sp[4], 128, 0, 0));
+    RC(L(t->sp[5], c.sp[5], c.out_sp[4], 128, c.out_sp[3], 128, c.out_sp[5], 128, 0, 0));
+    RC(L(t->sp[6], c.sp[6], c.out_sp[5], 128, nullptr, 0, c.out_sp[6], 64, 0, 0));
+    RC(L(t->sp[7], c.sp[7], c.out_sp[6], 64, nullptr, 0, c.out_sp[7], 64, 0, 0));
+    RC(L(t->sp[8], c.sp[8], c.out_sp[7], 64, c.out_sp[6], 64, c.ms, 64, 0, 1));
+    HIPCK(h, launch_space_apply(c.X, c.ms, 64, c.bufM, 1536, 0, imgs, st));
+    // Conv4Channel (recnet.py:372-386) on channelF_cat = [ss_channel | X^T] as six GEMMs
+    HIPCK(h, launch_ch_prep(c.X, c.Xt, c.Xht, c.cat, imgs, st));
+    RC(gemm_batched(h, w, c.Xht, 512 * 64, 64, c.Xht, 512 * 64, 512, c.cat, 576, (long long)512 * 576, 512, imgs, st));
+    const Lin* ln = t->lin;
+    RC(gemm_rows(h, w, c.cat, 576, 576, ln[0].w, ln[0].b, 64, c.h1pre, 64, crow, nullptr, 0, 0, st));
+    HIPCK(h, launch_prelu_rows(c.h1pre, c.h1, 64, 64, t->a[0], crow, st));
+    RC(gemm_rows(h, w, c.h1, 64, 32, ln[1].w, ln[1].b, 512, c.t2, 512, crow, nullptr, 0, 0, st));
+    RC(gemm_rows(h, w, c.t2, 512, 512, ln[2].w, ln[2].b, 64, c.h2pre, 64, crow, nullptr, 0, 0, st));
+    HIPCK(h, launch_prelu_rows(c.h2pre, c.h2, 64, 64, t->a[1], crow, st));
+    RC(gemm_rows(h, w, c.h2, 64, 32, ln[3].w, ln[3].b, 512, c.t5, 512, crow, nullptr, 0, 0, st));
+    RC(gemm_rows(h, w, c.t5, 512, 512, ln[4].w, ln[4].b, 64, c.h3pre, 64, crow, nullptr, 0, 0, st));
+    HIPCK(h, launch_prelu_rows(c.h3pre, c.h3, 64, 64, t->a[2], crow, st));
+    RC(gemm_rows(h, w, c.h3, 64, 32, ln[5].w, ln[5].b, 512, c.Mc, 512, crow, nullptr, 0, 1 /*sigmoid*/, st));
+    // feat_channel_raw = M_channel @ X (recnet.py:410), flip + cat (:416-417)
+    RC(gemm_batched(h, w, c.Mc, (long long)512 * 512, 512, c.X, 49 * 512, 64, c.raw, 64, 512 * 64, 512, imgs, st));
+    HIPCK(h, launch_raw_to_cat(c.raw, c.bufF, imgs, st));
+    // ChannelFlipMerge -> bufM[:, 512:1024]; Conv4Merge -> feat_new
+    RC(L(t->fm[0], c.fm[0], c.bufF, 1024, nullptr, 0, c.out_fm[0], 512, 0, 0));
+    RC(L(t->fm[1], c.fm[1], c.out_fm[0], 512, nullptr, 0, c.out_fm[1], 512, 0, 0));
+    RC(L(t->fm[2], c.fm[2], c.out_fm[1], 512, c.out_fm[0], 512, c.bufM, 1536, 512, 0));
+    RC(L(t->mg[0], c.mg[0], c.bufM, 1536, nullptr, 0, c.out_mg[0], 512, 0, 0));
+    RC(L(t->mg[1], c.mg[1], c.out_mg[0], 512, nullptr, 0, c.out_mg[1], 512, 0, 0));
+    RC(L(t->mg[2], c.mg[2], c.out_mg[1], 512, c.out_mg[0], 512, c.featnew, 512, 0, 0));
+    HIPCK(h, launch_avgpool49(c.featnew, c.fnew, imgs, 512, st));
+    // CosFace head (recnet.py:254-270)
+    HIPCK(h, launch_row_normalize(c.fnew, 512, c.fn, c.fnorm, imgs, st));
+    HIPCK(h, launch_row_normalize(t->clsW, 512, c.wn, c.wnorm, N_CLASSES, st));
+    RC(gemm_rows(h, w, c.fn, 512, 512, c.wn, nullptr, CLS_PAD, c.cosv, CLS_PAD, imgs, nullptr, 0, 0, st));
+    c.valid = true;
+    return FFR_OK;
+}
+
+// ---- backward ----------------------------------------------------------------------------------------
+struct OutGrads {
+    const float *f_new, *pred_loss, *pred_label, *M_space, *M_channel, *feat_space, *feat_channel;
+};
+
+int lin_backward(ffr_handle* h, TrainState* t, const Work& w, const Lin& ln, const float* dy, int dy_pitch, const float* x,
+                 int x_pitch, long long rows, float* dx, int dx_pitch, hipStream_t st) {
+    WgradArgs a{};
+    a.dy = dy; a.x = x; a.zero = h->zero; a.rows = (int)rows; a.H = 1; a.W = 1; a.x_pitch = x_pitch; a.dy_pitch = dy_pitch;
+    a.cin_pad = ln.in_pad; a.taps = 1; a.pad_mode = 0; a.cout_pad = ln.out_pad;
+    HIPCK(h, launch_wgrad(a, ln.gw, 1, t->sc.slabs, t->sc.slab_floats, st));
+    HIPCK(h, launch_colsum(dy, dy_pitch, (int)rows, ln.out_pad, ln.gb, 1, t->sc.part, st));
+    if (dx) {
+        // dx[rows][in] = dy[rows][out] * W  -> the kernel wants W^T as [in rounded to 64][K], K = out (32 or 512)
+        const int n_pad = round_up(ln.in_pad, 64);
+        const int kb = ln.out <= 32 ? 32 : ln.out_pad;
+        HIPCK(h, launch_transpose_pad(ln.w, kb, ln.in_pad, ln.in_pad, t->wT, n_pad, kb, st));
+        RC(gemm_rows(h, w, dy, dy_pitch, kb, t->wT, nullptr, n_pad, dx, dx_pitch, rows, nullptr, 0, 0, st));
+    }
+    return FFR_OK;
+}
+
+int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const OutGrads& og, hipStream_t st) {
+    const int G = c.G, N = c.N, imgs = G * N, rows = imgs * 49;
+    const long long crow = (long long)imgs * 512;
+    TScratch& s = t->sc;
+    auto LB = [&](const TLayer& Ly, const TSaved& sv, const float* da, int da_pitch, int da_coff, float* dx, int dx_pitch,
+                  int width, const float* add, int add_pitch, int add_coff) -> int {
+        return layer_backward(h, w, Ly, sv, G, N, da, da_pitch, da_coff, 1, s, dx, dx_pitch, 0, width, add, add_pitch, add_coff, st);
+    };
+    // ---- CosFace head and f_new ----------------------------------------------------------------
+    const float* df = og.f_new;
+    if (og.pred_loss || og.pred_label) {
+        HIPCK(h, launch_cosface_dcos(og.pred_loss, og.pred_label, t->dcos, CLS_PAD, imgs, N_CLASSES, COSFACE_S, st));
+        HIPCK(h, launch_transpose_pad(c.wn, CLS_PAD, 512, 512, t->wnT, 512, CLS_PAD, st));
+        RC(gemm_rows(h, w, t->dcos, CLS_PAD, CLS_PAD, t->wnT, nullptr, 512, t->dfn, 512, imgs, nullptr, 0, 0, st));
+        WgradArgs a{};
+        a.dy = t->dcos; a.x = c.fn; a.zero = h->zero; a.rows = imgs; a.H = 1; a.W = 1; a.x_pitch = 512; a.dy_pitch = CLS_PAD;
+        a.cin_pad = 512; a.taps = 1; a.pad_mode = 0; a.cout_pad = CLS_PAD;
+        HIPCK(h, launch_wgrad(a, t->dwn, 0, s.slabs, s.slab_floats, st));
+        HIPCK(h, launch_normalize_bwd(t->dwn, 512, c.wn, c.wnorm, nullptr, t->gclsW, 512, 1, N_CLASSES, st));
+        HIPCK(h, launch_normalize_bwd(t->dfn, 512, c.fn, c.fnorm, og.f_new, t->df, 512, 0, imgs, st));
+        df = t->df;
+    }
+    if (df) HIPCK(h, launch_avgpool_bwd(df, nullptr, t->dFeatNew, imgs, 512, st));
+    else HIPCK(h, hipMemsetAsync(t->dFeatNew, 0, (size_t)rows * 512 * 4, st));
+    // external gradients wrt feat_space / feat_channel (NCHW) -> extM [rows][1024]
+    if (og.feat_space) HIPCK(h, launch_nchw_to_nhwc(og.feat_space, t->extM, 1024, imgs, 49, 512, st));
+    else HIPCK(h, launch_fill(t->extM, 0.f, (size_t)rows * 1024, st));
+    if (og.feat_channel) HIPCK(h, launch_nchw_to_nhwc(og.feat_channel, t->extM + 512, 1024, imgs, 49, 512, st));
+    else if (og.feat_space) {
+        // zero the second half only
+        HIPCK(h, hipMemset2DAsync(t->extM + 512, 1024 * 4, 0, 512 * 4, rows, st));
+    }
+    // ---- Conv4Merge ------------------------------------------------------------------------------
+    RC(LB(t->mg[2], c.mg[2], t->dFeatNew, 512, 0, t->d512a, 512, 512, nullptr, 0, 0));
+    RC(LB(t->mg[1], c.mg[1], t->d512a, 512, 0, t->d512b, 512, 512, t->dFeatNew, 512, 0));
+    RC(LB(t->mg[0], c.mg[0], t->d512b, 512, 0, t->dBufM, 1024, 1024, t->extM, 1024, 0));
+    // ---- ChannelFlipMerge ------------------------------------------------------------------------
+    RC(LB(t->fm[2], c.fm[2], t->dBufM, 1024, 512, t->d512a, 512, 512, nullptr, 0, 0));
+    RC(LB(t->fm[1], c.fm[1], t->d512a, 512, 0, t->d512b, 512, 512, t->dBufM, 1024, 512));
+    RC(LB(t->fm[0], c.fm[0], t->d512b, 512, 0, t->dF, 1024, 1024, nullptr, 0, 0));
+    // ---- M_channel: feat_channel_raw = M_channel @ X -------------------------------------------
+    HIPCK(h, launch_cat_to_draw(t->dF, t->dRawt, imgs, st));
+    RC(gemm_batched(h, w, t->dRawt, 512 * 64, 64, c.Xt, 512 * 64, 512, t->dMc, 512, (long long)512 * 512, 512, imgs, st));
+    HIPCK(h, launch_sigmoid_bwd_ext(t->dMc, og.M_channel, c.Mc, (size_t)crow * 512, st));
+    // ---- Conv4Channel, last linear first -------------------------------------------------------
+    const Lin* ln = t->lin;
+    RC(lin_backward(h, t, w, ln[5], t->dMc, 512, c.h3, 64, crow, t->d32a, 64, st));
+    HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h3pre, 64, 64, t->a[2], crow, t->rowdot, t->ga[2], 1, st));
+    RC(lin_backward(h, t, w, ln[4], t->d32a, 64, c.t5, 512, crow, t->dt, 512, st));
+    RC(lin_backward(h, t, w, ln[3], t->dt, 512, c.h2, 64, crow, t->d32b, 64, st));
+    HIPCK(h, launch_prelu_rows_bwd(t->d32b, c.h2pre, 64, 64, t->a[1], crow, t->rowdot, t->ga[1], 1, st));
+    RC(lin_backward(h, t, w, ln[2], t->d32b, 64, c.t2, 512, crow, t->dt, 512, st));
+    RC(lin_backward(h, t, w, ln[1], t->dt, 512, c.h1, 64, crow, t->d32a, 64, st));
+    HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h1pre, 64, 64, t->a[0], crow, t->rowdot, t->ga[0], 1, st));
+    RC(lin_backward(h, t, w, ln[0], t->d32a, 64, c.cat, 576, crow, nullptr, 0, st));
+    // ---- M_space: feat_space = X_flat @ M_space ------------------------------------------------
+    HIPCK(h, launch_space_apply_bwd(t->dBufM, 1024, 0, c.X, t->dms, imgs, st));
+    if (og.M_space) HIPCK(h, launch_mspace_grad_in(og.M_space, t->dms, imgs, st));
+    HIPCK(h, launch_sigmoid_bwd(t->dms, 64, c.ms, 64, rows, 64, st));
+    // ---- Conv4Space ------------------------------------------------------------------------------
+    RC(LB(t->sp[8], c.sp[8], t->dms, 64, 0, t->d256a, 64, 64, nullptr, 0, 0));
+    RC(LB(t->sp[7], c.sp[7], t->d256a, 64, 0, t->d256b, 64, 64, t->dms, 64, 0));
+    RC(LB(t->sp[6], c.sp[6], t->d256b, 64, 0, t->d256c, 128, 128, nullptr, 0, 0));
+    RC(LB(t->sp[5], c.sp[5], t->d256c, 128, 0, t->d256a, 128, 128, nullptr, 0, 0));
+    RC(LB(t->sp[4], c.sp[4], t->d256a, 128, 0, t->d256b, 128, 128, t->d256c, 128, 0));
+    RC(LB(t->sp[3], c.sp[3], t->d256b, 128, 0, t->d256c, 256, 256, nullptr, 0, 0));
+    RC(LB(t->sp[2], c.sp[2], t->d256c, 256, 0, t->d256a, 256, 256, nullptr, 0, 0));
+    RC(LB(t->sp[1], c.sp[1], t->d256a, 256, 0, t->d256b, 256, 256, t->d256c, 256, 0));
+    RC(LB(t->sp[0], c.sp[0], t->d256b, 256, 0, nullptr, 0, 0, nullptr, 0, 0));
+    return FFR_OK;
+}
+
+}  // namespace
 
 void train_free(ffr_handle* h) {
     if (!h || !h->train) return;
+    hipDeviceSynchronize();
+    for (auto& c : h->train->ctx) free_ctx(c);
+    if (h->train->scratch_mem) hipFree(h->train->scratch_mem);
     free_list(h->train->allocs);
     delete h->train;
     h->train = nullptr;
@@ -189,6 +545,241 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
     if (dvec) HIPCK(h, hipMemcpyAsync(dvec, gv, (size_t)5 * L.cout_pad * 4, hipMemcpyDeviceToDevice, st));
     if (stats) HIPCK(h, hipMemcpyAsync(stats, sv.bn.mean, (size_t)2 * G * L.cout_pad * 4, hipMemcpyDeviceToDevice, st));
     HIPCK(h, hipStreamSynchronize(st));
+    return FFR_OK;
+}
+
+
+int ffr_train_init(ffr_handle* h, const ffr_tensor_desc* td, int n) {
+    if (!h || !td || n <= 0) return fail(h, FFR_ERR_ARG, "ffr_train_init: bad arguments");
+    RC(check_fwd(h, false, false, 1));
+    train_free(h);
+    TrainState* t = new TrainState();
+    h->train = t;
+    SD sd; sd.h = h;
+    for (int i = 0; i < n; ++i) if (td[i].name) sd.m[td[i].name] = &td[i];
+    // ---- layout of the flat parameter buffer --------------------------------------------------
+    size_t running_floats = 0;
+    auto def_layers = [&](const LayerDef* defs, int cnt, TLayer* out) {
+        for (int i = 0; i < cnt; ++i) {
+            TLayer& L = out[i];
+            L.cin = defs[i].cin; L.cout = defs[i].cout; L.cin_pad = round_up(L.cin, 32); L.cout_pad = round_up(L.cout, 64);
+            const std::string p = defs[i].p;
+            add_seg(t, p + ".conv2d.weight", SEG_CONV, L.cout, L.cin, L.cout_pad, L.cin_pad);
+            add_seg(t, p + ".relu.func.weight", SEG_VEC, L.cout, 1, L.cout_pad, 1);
+            add_seg(t, p + ".norm.norm.weight", SEG_VEC, L.cout, 1, L.cout_pad, 1);
+            add_seg(t, p + ".norm.norm.bias", SEG_VEC, L.cout, 1, L.cout_pad, 1);
+            running_floats += (size_t)2 * L.cout_pad;
+        }
+    };
+    def_layers(SP_DEF, 9, t->sp);
+    def_layers(FM_DEF, 3, t->fm);
+    def_layers(MG_DEF, 3, t->mg);
+    for (int i = 0; i < 6; ++i) {
+        Lin& l = t->lin[i];
+        l.in = LIN_IN[i]; l.out = LIN_OUT[i]; l.in_pad = round_up(l.in, 32); l.out_pad = round_up(l.out, 64);
+        const std::string p = "Conv4Channel." + std::to_string(LIN_IDX[i]);
+        add_seg(t, p + ".weight", SEG_LIN, l.out, l.in, l.out_pad, l.in_pad, i == 0 ? 1 : 0);
+        add_seg(t, p + ".bias", SEG_VEC, l.out, 1, l.out_pad, 1);
+    }
+    for (int i = 0; i < 3; ++i) add_seg(t, "Conv4Channel." + std::to_string(ACT_IDX[i]) + ".func.weight", SEG_VEC, 512, 1, 512, 1);
+    add_seg(t, "classifier.weight", SEG_LIN, N_CLASSES, 512, CLS_PAD, 512);
+    // ---- device buffers ---------------------------------------------------------------------------
+    RC(dev_alloc_t(h, t->allocs, t->n_flat, &t->P));
+    RC(dev_alloc_t(h, t->allocs, t->n_flat, &t->Gr));
+    RC(dev_alloc_t(h, t->allocs, t->n_flat, &t->M1));
+    RC(dev_alloc_t(h, t->allocs, t->n_flat, &t->M2));
+    RC(dev_alloc_t(h, t->allocs, running_floats, &t->running));
+    HIPCK(h, hipMemset(t->Gr, 0, t->n_flat * 4));
+    HIPCK(h, hipMemset(t->M1, 0, t->n_flat * 4));
+    HIPCK(h, hipMemset(t->M2, 0, t->n_flat * 4));
+    // ---- parameters: natural layout (host) -> native layout ------------------------------------------
+    std::vector<float> flat(t->n_flat, 0.f);
+    for (const Seg& sg : t->segs) {
+        const float* src = nullptr;
+        if (sg.kind == SEG_CONV) src = sd.get(sg.key, {sg.d0, sg.d1, 3, 3});
+        else if (sg.kind == SEG_VEC) src = sd.get(sg.key, {sg.d0});
+        else src = sd.get(sg.key, {sg.d0, sg.d1});
+        if (!src) return sd.rc;
+        for (size_t i = 0; i < sg.n_natural; ++i) flat[sg.off + sg.native_index(i)] = src[i];
+    }
+    HIPCK(h, hipMemcpy(t->P, flat.data(), t->n_flat * 4, hipMemcpyHostToDevice));
+    std::vector<float> run(running_floats, 0.f);
+    size_t roff = 0;
+    auto bind_layers = [&](const LayerDef* defs, int cnt, TLayer* out) -> int {
+        for (int i = 0; i < cnt; ++i) {
+            TLayer& L = out[i];
+            const std::string p = defs[i].p;
+            auto ptr = [&](const std::string& k, float* base) { return base + t->segs[t->seg_of[k]].off; };
+            L.w = ptr(p + ".conv2d.weight", t->P); L.gw = ptr(p + ".conv2d.weight", t->Gr);
+            L.slope = ptr(p + ".relu.func.weight", t->P); L.gslope = ptr(p + ".relu.func.weight", t->Gr);
+            L.gamma = ptr(p + ".norm.norm.weight", t->P); L.ggamma = ptr(p + ".norm.norm.weight", t->Gr);
+            L.beta = ptr(p + ".norm.norm.bias", t->P); L.gbeta = ptr(p + ".norm.norm.bias", t->Gr);
+            const float* rm = sd.get(p + ".norm.norm.running_mean", {L.cout});
+            const float* rv = sd.get(p + ".norm.norm.running_var", {L.cout});
+            if (!rm || !rv) return sd.rc;
+            L.rmean = t->running + roff; L.rvar = t->running + roff + L.cout_pad;
+            for (int c = 0; c < L.cout; ++c) { run[roff + c] = rm[c]; run[roff + L.cout_pad + c] = rv[c]; }
+            t->running_of[p + ".norm.norm.running_mean"] = {L.rmean, L.cout};
+            t->running_of[p + ".norm.norm.running_var"] = {L.rvar, L.cout};
+            roff += (size_t)2 * L.cout_pad;
+        }
+        return FFR_OK;
+    };
+    RC(bind_layers(SP_DEF, 9, t->sp));
+    RC(bind_layers(FM_DEF, 3, t->fm));
+    RC(bind_layers(MG_DEF, 3, t->mg));
+    HIPCK(h, hipMemcpy(t->running, run.data(), running_floats * 4, hipMemcpyHostToDevice));
+    for (int i = 0; i < 6; ++i) {
+        Lin& l = t->lin[i];
+        const std::string p = "Conv4Channel." + std::to_string(LIN_IDX[i]);
+        const size_t ow = t->segs[t->seg_of[p + ".weight"]].off, ob = t->segs[t->seg_of[p + ".bias"]].off;
+        l.w = t->P + ow; l.gw = t->Gr + ow; l.b = t->P + ob; l.gb = t->Gr + ob;
+    }
+    for (int i = 0; i < 3; ++i) {
+        const size_t o = t->segs[t->seg_of["Conv4Channel." + std::to_string(ACT_IDX[i]) + ".func.weight"]].off;
+        t->a[i] = t->P + o; t->ga[i] = t->Gr + o;
+    }
+    {
+        const size_t o = t->segs[t->seg_of["classifier.weight"]].off;
+        t->clsW = t->P + o; t->gclsW = t->Gr + o;
+    }
+    t->adam_step = 0;
+    t->nbt = 0;
+    return FFR_OK;
+}
+
+int ffr_train_info(ffr_handle* h, float** params, float** grads, size_t* n_flat, long long* num_batches_tracked,
+                   int* adam_step) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (params) *params = t->P;
+    if (grads) *grads = t->Gr;
+    if (n_flat) *n_flat = t->n_flat;
+    if (num_batches_tracked) *num_batches_tracked = t->nbt;
+    if (adam_step) *adam_step = t->adam_step;
+    return FFR_OK;
+}
+
+int ffr_train_get(ffr_handle* h, int which, const char* key, float* host_out, size_t n) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (!key || !host_out) return fail(h, FFR_ERR_ARG, "ffr_train_get: null argument");
+    HIPCK(h, hipDeviceSynchronize());
+    if (which == 4) {
+        auto it = t->running_of.find(key);
+        if (it == t->running_of.end()) return fail(h, FFR_ERR_KEY, "no running statistic '%s'", key);
+        if ((size_t)it->second.second != n) return fail(h, FFR_ERR_ARG, "'%s' has %d elements, not %zu", key, it->second.second, n);
+        HIPCK(h, hipMemcpy(host_out, it->second.first, n * 4, hipMemcpyDeviceToHost));
+        return FFR_OK;
+    }
+    auto it = t->seg_of.find(key);
+    if (it == t->seg_of.end()) return fail(h, FFR_ERR_KEY, "no parameter '%s'", key);
+    const Seg& sg = t->segs[it->second];
+    if (sg.n_natural != n) return fail(h, FFR_ERR_ARG, "'%s' has %zu elements, not %zu", key, sg.n_natural, n);
+    const float* base = which == 0 ? t->P : which == 1 ? t->Gr : which == 2 ? t->M1 : which == 3 ? t->M2 : nullptr;
+    if (!base) return fail(h, FFR_ERR_ARG, "ffr_train_get: which must be 0..4");
+    std::vector<float> nat(sg.n_native);
+    HIPCK(h, hipMemcpy(nat.data(), base + sg.off, sg.n_native * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) host_out[i] = nat[sg.native_index(i)];
+    return FFR_OK;
+}
+
+int ffr_train_set(ffr_handle* h, int which, const char* key, const float* host_in, size_t n) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (!key || !host_in) return fail(h, FFR_ERR_ARG, "ffr_train_set: null argument");
+    HIPCK(h, hipDeviceSynchronize());
+    auto it = t->seg_of.find(key);
+    if (it == t->seg_of.end()) return fail(h, FFR_ERR_KEY, "no parameter '%s'", key);
+    const Seg& sg = t->segs[it->second];
+    if (sg.n_natural != n) return fail(h, FFR_ERR_ARG, "'%s' has %zu elements, not %zu", key, sg.n_natural, n);
+    float* base = which == 0 ? t->P : which == 1 ? t->Gr : which == 2 ? t->M1 : which == 3 ? t->M2 : nullptr;
+    if (!base) return fail(h, FFR_ERR_ARG, "ffr_train_set: which must be 0..3");
+    std::vector<float> nat(sg.n_native, 0.f);
+    for (size_t i = 0; i < n; ++i) nat[sg.native_index(i)] = host_in[i];
+    HIPCK(h, hipMemcpy(base + sg.off, nat.data(), sg.n_native * 4, hipMemcpyHostToDevice));
+    return FFR_OK;
+}
+
+int ffr_train_zero_grad(ffr_handle* h, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, (hipStream_t)stream));
+    return FFR_OK;
+}
+
+int ffr_train_forward(ffr_handle* h, int slot, const float* featmap_nchw, const int32_t* label, int G, int N,
+                      float* f_new, float* pred_loss, float* pred_label, float* M_space, float* M_channel,
+                      float* feat_space, float* feat_channel, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (slot < 0 || slot > 1 || !featmap_nchw || G <= 0 || N <= 0 || ((pred_loss || pred_label) && !label))
+        return fail(h, FFR_ERR_ARG, "ffr_train_forward: bad arguments");
+    if (N * 49 < 2) return fail(h, FFR_ERR_ARG, "ffr_train_forward: batch statistics need more than one value per channel");
+    hipStream_t st = (hipStream_t)stream;
+    const int imgs = G * N;
+    Work w;
+    RC(ensure_arena(h, imgs, 112, 112, &w));
+    RC(ensure_scratch(h, t, imgs));
+    Ctx& c = t->ctx[slot];
+    RC(ensure_ctx(h, t, c, G, N));
+    HIPCK(h, launch_nchw_to_nhwc(featmap_nchw, c.X, 512, imgs, 49, 512, st));
+    if (label) HIPCK(h, hipMemcpyAsync(c.label, label, (size_t)imgs * 4, hipMemcpyDeviceToDevice, st));
+    RC(train_forward(h, t, c, w, st));
+    if (f_new) HIPCK(h, hipMemcpyAsync(f_new, c.fnew, (size_t)imgs * 512 * 4, hipMemcpyDeviceToDevice, st));
+    if (pred_loss || pred_label)
+        HIPCK(h, launch_cosface_out(c.cosv, CLS_PAD, c.label, pred_loss, pred_label, imgs, N_CLASSES, COSFACE_S, COSFACE_M, st));
+    if (M_space) HIPCK(h, launch_mspace_out(c.ms, M_space, imgs, st));
+    if (M_channel) HIPCK(h, hipMemcpyAsync(M_channel, c.Mc, (size_t)imgs * 512 * 512 * 4, hipMemcpyDeviceToDevice, st));
+    if (feat_space) HIPCK(h, launch_nhwc_to_nchw(c.bufM, 1536, feat_space, imgs, 49, 512, st));
+    if (feat_channel) HIPCK(h, launch_nhwc_to_nchw(c.bufM + 512, 1536, feat_channel, imgs, 49, 512, st));
+    return FFR_OK;
+}
+
+int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const float* d_pred_loss, const float* d_pred_label,
+                       const float* d_M_space, const float* d_M_channel, const float* d_feat_space,
+                       const float* d_feat_channel, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (slot < 0 || slot > 1) return fail(h, FFR_ERR_ARG, "ffr_train_backward: bad slot");
+    Ctx& c = t->ctx[slot];
+    if (!c.valid) return fail(h, FFR_ERR_STATE, "ffr_train_backward: no forward recorded in slot %d", slot);
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, c.G * c.N, 112, 112, &w));
+    RC(ensure_scratch(h, t, c.G * c.N));
+    OutGrads og{d_f_new, d_pred_loss, d_pred_label, d_M_space, d_M_channel, d_feat_space, d_feat_channel};
+    RC(train_backward(h, t, c, w, og, st));
+    c.valid = false;
+    return FFR_OK;
+}
+
+int ffr_train_adam_step(ffr_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value,
+                        void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    t->adam_step += 1;
+    HIPCK(h, launch_adam(t->P, t->Gr, t->M1, t->M2, t->n_flat, lr, beta1, beta2, eps, weight_decay,
+                         clip_value > 0.f ? clip_value : 3.0e38f, t->adam_step, (hipStream_t)stream));
+    return FFR_OK;
+}
+
+
+// Test hook: copy a named intermediate of context `slot` (or of the backward scratch) to the host.
+int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_out, size_t n) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (slot < 0 || slot > 1 || !name || !host_out) return fail(h, FFR_ERR_ARG, "ffr_train_debug_copy: bad arguments");
+    Ctx& c = t->ctx[slot];
+    if (!c.mem) return fail(h, FFR_ERR_STATE, "no forward in slot %d", slot);
+    const std::string k = name;
+    const float* src = k == "cat" ? c.cat : k == "h1pre" ? c.h1pre : k == "h1" ? c.h1 : k == "t2" ? c.t2 : k == "h2pre" ? c.h2pre :
+                       k == "h3pre" ? c.h3pre : k == "Mc" ? c.Mc : k == "raw" ? c.raw : k == "X" ? c.X : k == "Xht" ? c.Xht :
+                       k == "d32a" ? t->d32a : k == "d32b" ? t->d32b : k == "dMc" ? t->dMc : k == "dt" ? t->dt :
+                       k == "dBufM" ? t->dBufM : k == "dF" ? t->dF : k == "dms" ? t->dms : nullptr;
+    if (!src) return fail(h, FFR_ERR_KEY, "no intermediate named '%s'", name);
+    HIPCK(h, hipDeviceSynchronize());
+    HIPCK(h, hipMemcpy(host_out, src, n * 4, hipMemcpyDeviceToHost));
     return FFR_OK;
 }
 

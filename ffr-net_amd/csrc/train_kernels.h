@@ -62,5 +62,54 @@ hipError_t launch_sigmoid_bwd(float* g, int g_pitch, const float* s, int s_pitch
 // d feat[n][p][c] = df[n][c] / 49 (+ add[n][p][c])     (AvgPool2d(7) backward)
 hipError_t launch_avgpool_bwd(const float* df, const float* add, float* out, int N, int C, hipStream_t stream);
 hipError_t launch_fill(float* p, float v, size_t n, hipStream_t stream);
+// g = (g + ext) * s * (1 - s) on compact [n] arrays (ext may be null)
+hipError_t launch_sigmoid_bwd_ext(float* g, const float* ext, const float* s, size_t n, hipStream_t stream);
+// out[c] (+)= sum_rows x[row][c]; part: scratch of bn_part_doubles(1, rows, Cp) doubles; Cp % 64 == 0
+hipError_t launch_colsum(const float* x, int pitch, int rows, int Cp, float* out, int accumulate, double* part,
+                         hipStream_t stream);
+// Wt[c][r] = W[r][c] for r < R, c < C; Wt is [Cp][Rp], zero elsewhere
+hipError_t launch_transpose_pad(const float* W, int R, int C, int w_pitch, float* Wt, int Cp, int Rp, hipStream_t stream);
+
+// ---- Conv4Channel (models/recnet.py:372-386) as GEMMs: layout helpers ----------------------------------
+// per image X[49][512] (NHWC rows): Xt[c][p] (pad 64, zeros), Xht = rows of Xt divided by max(norm, 1e-12)
+// (F.normalize over the 49 positions, cosine_sim models/recnet.py:220-224), cat[n*512 + c][512 + p] = Xt[c][p]
+// for p < 49 and zeros up to column 576 (channelF_cat with the two column blocks swapped)
+hipError_t launch_ch_prep(const float* X, float* Xt, float* Xht, float* cat, int imgs, hipStream_t stream);
+// PReLU whose slope is indexed by the ROW (row % 512), nn.PReLU(512) applied to [N,512,32] (recnet.py:374)
+hipError_t launch_prelu_rows(const float* x, float* out, int pitch, int C, const float* slope, long long rows,
+                             hipStream_t stream);
+// dx = dy * (x > 0 ? 1 : slope[row % 512]) in place over dy; dslope[c] (+)= sum_{n,o} dy*min(x,0); rowdot: scratch [rows]
+hipError_t launch_prelu_rows_bwd(float* dy, const float* x, int pitch, int C, const float* slope, long long rows,
+                                 float* rowdot, float* dslope, int accumulate, hipStream_t stream);
+// raw[n][c][p] (pitch 64) -> bufF[n*49 + p][512 + c] and bufF[n*49 + flipW(p)][c]   (recnet.py:416-417)
+hipError_t launch_raw_to_cat(const float* raw, float* bufF, int imgs, hipStream_t stream);
+// adjoint: draw[n][c][p] = dF[n*49+p][512+c] + dF[n*49+flipW(p)][c], zeros for p >= 49
+hipError_t launch_cat_to_draw(const float* dF, float* draw, int imgs, hipStream_t stream);
+// d ms[n][j][i] = sum_c dFS[n*49+j][coff + c] * X[n*49+i][c]  (i, j < 49; channels >= 49 of the pitch-64 row zero)
+hipError_t launch_space_apply_bwd(const float* dFS, int d_pitch, int d_coff, const float* X, float* dms, int imgs,
+                                  hipStream_t stream);
+
+// M_space[n][i][j] = ms[n*49 + j][i] (ms pitch 64): the [N,49,49] view of models/recnet.py:405
+hipError_t launch_mspace_out(const float* ms, float* M_space, int imgs, hipStream_t stream);
+// adjoint: dms[n*49 + j][i] += dM[n][i][j]
+hipError_t launch_mspace_grad_in(const float* dM, float* dms, int imgs, hipStream_t stream);
+
+// ---- CosFace head (AddMarginProduct, models/recnet.py:238-270) --------------------------------------------
+// v[row] = u[row] / max(|u[row]|, 1e-12), norm[row] = that denominator   (C = 512)
+hipError_t launch_row_normalize(const float* u, int u_pitch, float* v, float* norm, int rows, hipStream_t stream);
+// pred_label[n][k] = cos[n][k]; pred_loss[n][k] = s * (cos - m * (k == label[n]))   (compact [imgs][classes])
+hipError_t launch_cosface_out(const float* cos, int cos_pitch, const int* label, float* pred_loss, float* pred_label,
+                              int imgs, int classes, float s, float m, hipStream_t stream);
+// dcos[n][k] = s * d_pred_loss[n][k] + d_pred_label[n][k]  (either may be null), zeros for k >= classes
+hipError_t launch_cosface_dcos(const float* d_pred_loss, const float* d_pred_label, float* dcos, int cos_pitch, int imgs,
+                               int classes, float s, hipStream_t stream);
+// du[row] (+)= (dv - v * <v, dv>) / norm[row] (+ ext[row])    (C = 512; backward of the row normalisation)
+hipError_t launch_normalize_bwd(const float* dv, int dv_pitch, const float* v, const float* norm, const float* ext,
+                                float* du, int du_pitch, int accumulate, int rows, hipStream_t stream);
+
+// ---- optimiser (models/trainer.py:115-121,182-187) -----------------------------------------------------
+// clip_grad_value_(clip) then torch.optim.Adam: p, g, m, v flat arrays of n floats; step counts from 1
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float clip, int step, hipStream_t stream);
 
 }  // namespace ffr

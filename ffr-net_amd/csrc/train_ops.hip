@@ -352,3 +352,411 @@ hipError_t launch_fill(float* p, float v, size_t n, hipStream_t stream) {
 }
 
 }  // namespace ffr
+
+// =====================================================================================================
+// second part: Conv4Channel layout helpers, CosFace head, optimiser
+namespace ffr {
+
+__global__ __launch_bounds__(256) void k_sigmoid_bwd_ext(float* __restrict__ g, const float* __restrict__ ext,
+                                                        const float* __restrict__ s, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 gv = reinterpret_cast<f32x4*>(g)[i];
+    if (ext) gv += reinterpret_cast<const f32x4*>(ext)[i];
+    const f32x4 sv = reinterpret_cast<const f32x4*>(s)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gv[e] *= sv[e] * (1.f - sv[e]);
+    reinterpret_cast<f32x4*>(g)[i] = gv;
+}
+
+hipError_t launch_sigmoid_bwd_ext(float* g, const float* ext, const float* s, size_t n, hipStream_t stream) {
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sigmoid_bwd_ext, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, g, ext, s, n / 4);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int pitch, int rows, int Cp,
+                                                       double* __restrict__ part) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int s = blockIdx.y;
+    const int r0 = s * SLICE_ROWS;
+    const int r1 = min(r0 + SLICE_ROWS, rows);
+    double a = 0.0;
+    for (int r = r0 + rl; r < r1; r += 4) a += (double)x[(size_t)r * pitch + c];
+    __shared__ double sh[4][64];
+    sh[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        part[(size_t)s * Cp + c] = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_colsum_final(const double* __restrict__ part, int Cp, int nsl, float* out,
+                                                    int accumulate) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= Cp) return;
+    double a = 0.0;
+    for (int s = 0; s < nsl; ++s) a += part[(size_t)s * Cp + c];
+    if (accumulate) a += out[c];
+    out[c] = (float)a;
+}
+
+hipError_t launch_colsum(const float* x, int pitch, int rows, int Cp, float* out, int accumulate, double* part,
+                         hipStream_t stream) {
+    if (Cp % 64) return hipErrorInvalidValue;
+    const int nsl = n_slices(rows);
+    hipLaunchKernelGGL(k_colsum_partial, dim3(Cp / 64, nsl), dim3(256), 0, stream, x, pitch, rows, Cp, part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(Cp / 64), dim3(64), 0, stream, part, Cp, nsl, out, accumulate);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_transpose_pad(const float* __restrict__ W, int R, int C, int w_pitch,
+                                                      float* __restrict__ Wt, int Cp, int Rp) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? W[(size_t)r * w_pitch + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cp && r < Rp) Wt[(size_t)c * Rp + r] = tile[tx][i];
+    }
+}
+
+hipError_t launch_transpose_pad(const float* W, int R, int C, int w_pitch, float* Wt, int Cp, int Rp, hipStream_t stream) {
+    hipLaunchKernelGGL(k_transpose_pad, dim3((Cp + 31) / 32, (Rp + 31) / 32), dim3(256), 0, stream, W, R, C, w_pitch, Wt,
+                       Cp, Rp);
+    return hipGetLastError();
+}
+
+// one block per (image, 32-channel group): tile X[49][32] through LDS
+__global__ __launch_bounds__(256) void k_ch_prep(const float* __restrict__ X, float* __restrict__ Xt,
+                                                float* __restrict__ Xht, float* __restrict__ cat) {
+    __shared__ float t[49][33];
+    __shared__ float inv[32];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int p = ty; p < 49; p += 8) t[p][tx] = X[((size_t)n * 49 + p) * 512 + c0 + tx];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int p = 0; p < 49; ++p) s += t[p][threadIdx.x] * t[p][threadIdx.x];
+        inv[threadIdx.x] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    }
+    __syncthreads();
+    // 32 channels x 64 positions, lanes along the positions
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        const float v = p < 49 ? t[p][c] : 0.f;
+        const size_t row = (size_t)n * 512 + c0 + c;
+        Xt[row * 64 + p] = v;
+        Xht[row * 64 + p] = v * inv[c];
+        cat[row * 576 + 512 + p] = v;
+    }
+}
+
+hipError_t launch_ch_prep(const float* X, float* Xt, float* Xht, float* cat, int imgs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ch_prep, dim3(16, imgs), dim3(256), 0, stream, X, Xt, Xht, cat);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_prelu_rows(const float* __restrict__ x, float* __restrict__ out, int pitch, int cq,
+                                                   const float* __restrict__ slope, long long total4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const long long row = idx / cq;
+    const int c = (int)(idx - row * cq) * 4;
+    const float sl = slope[row & 511];
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + row * pitch + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * sl;
+    *reinterpret_cast<f32x4*>(out + row * pitch + c) = v;
+}
+
+hipError_t launch_prelu_rows(const float* x, float* out, int pitch, int C, const float* slope, long long rows,
+                             hipStream_t stream) {
+    if ((pitch | C) & 3) return hipErrorInvalidValue;
+    const long long total4 = rows * (C >> 2);
+    hipLaunchKernelGGL(k_prelu_rows, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, x, out, pitch, C >> 2,
+                       slope, total4);
+    return hipGetLastError();
+}
+
+// one thread per row (C <= 64 columns): in-place gradient + the row's contribution to dslope
+__global__ __launch_bounds__(256) void k_prelu_rows_bwd(float* __restrict__ dy, const float* __restrict__ x, int pitch,
+                                                       int C, const float* __restrict__ slope, long long rows,
+                                                       float* __restrict__ rowdot) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float sl = slope[row & 511];
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 4) {
+        f32x4 d = *reinterpret_cast<f32x4*>(dy + row * pitch + c);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * pitch + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!(xv[e] > 0.f)) { acc += d[e] * xv[e]; d[e] *= sl; }
+        }
+        *reinterpret_cast<f32x4*>(dy + row * pitch + c) = d;
+    }
+    rowdot[row] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_rowdot_to_slope(const float* __restrict__ rowdot, long long imgs, float* dslope,
+                                                        int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 512) return;
+    double a = 0.0;
+    for (long long n = 0; n < imgs; ++n) a += (double)rowdot[n * 512 + c];
+    if (accumulate) a += dslope[c];
+    dslope[c] = (float)a;
+}
+
+hipError_t launch_prelu_rows_bwd(float* dy, const float* x, int pitch, int C, const float* slope, long long rows,
+                                 float* rowdot, float* dslope, int accumulate, hipStream_t stream) {
+    if ((pitch | C) & 3 || rows % 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_prelu_rows_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, dy, x, pitch, C, slope,
+                       rows, rowdot);
+    hipLaunchKernelGGL(k_rowdot_to_slope, dim3(2), dim3(256), 0, stream, rowdot, rows / 512, dslope, accumulate);
+    return hipGetLastError();
+}
+
+// block per (image, 32-channel group)
+__global__ __launch_bounds__(256) void k_raw_to_cat(const float* __restrict__ raw, float* __restrict__ bufF) {
+    __shared__ float t[32][65];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        t[c][p] = raw[((size_t)n * 512 + c0 + c) * 64 + p];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int p = ty; p < 49; p += 8) {
+        const int h = p / 7, w = p - h * 7;
+        const float v = t[tx][p];
+        bufF[((size_t)n * 49 + p) * 1024 + 512 + c0 + tx] = v;
+        bufF[((size_t)n * 49 + h * 7 + (6 - w)) * 1024 + c0 + tx] = v;
+    }
+}
+
+hipError_t launch_raw_to_cat(const float* raw, float* bufF, int imgs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_raw_to_cat, dim3(16, imgs), dim3(256), 0, stream, raw, bufF);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_cat_to_draw(const float* __restrict__ dF, float* __restrict__ draw) {
+    __shared__ float t[32][65];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int p = ty; p < 64; p += 8) {
+        float v = 0.f;
+        if (p < 49) {
+            const int h = p / 7, w = p - h * 7;
+            v = dF[((size_t)n * 49 + p) * 1024 + 512 + c0 + tx] + dF[((size_t)n * 49 + h * 7 + (6 - w)) * 1024 + c0 + tx];
+        }
+        t[tx][p] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        draw[((size_t)n * 512 + c0 + c) * 64 + p] = t[c][p];
+    }
+}
+
+hipError_t launch_cat_to_draw(const float* dF, float* draw, int imgs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_cat_to_draw, dim3(16, imgs), dim3(256), 0, stream, dF, draw);
+    return hipGetLastError();
+}
+
+// block per image; thread per (j, i) pair in turn; both rows are contiguous 512-vectors
+__global__ __launch_bounds__(256) void k_space_apply_bwd(const float* __restrict__ dFS, int d_pitch, int d_coff,
+                                                        const float* __restrict__ X, float* __restrict__ dms) {
+    const int n = blockIdx.x;
+    for (int o = threadIdx.x; o < 49 * 64; o += 256) {
+        const int j = o >> 6, i = o & 63;
+        float acc = 0.f;
+        if (i < 49) {
+            const f32x4* a = reinterpret_cast<const f32x4*>(dFS + ((size_t)n * 49 + j) * d_pitch + d_coff);
+            const f32x4* b = reinterpret_cast<const f32x4*>(X + ((size_t)n * 49 + i) * 512);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 128; ++c) s += a[c] * b[c];
+            acc = (s[0] + s[1]) + (s[2] + s[3]);
+        }
+        dms[((size_t)n * 49 + j) * 64 + i] = acc;
+    }
+}
+
+hipError_t launch_space_apply_bwd(const float* dFS, int d_pitch, int d_coff, const float* X, float* dms, int imgs,
+                                  hipStream_t stream) {
+    if ((d_pitch | d_coff) & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_space_apply_bwd, dim3(imgs), dim3(256), 0, stream, dFS, d_pitch, d_coff, X, dms);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_mspace_out(const float* __restrict__ ms, float* __restrict__ M, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int n = idx / 2401, r = idx - n * 2401;
+    const int i = r / 49, j = r - i * 49;
+    M[idx] = ms[((size_t)n * 49 + j) * 64 + i];
+}
+
+hipError_t launch_mspace_out(const float* ms, float* M_space, int imgs, hipStream_t stream) {
+    const int total = imgs * 2401;
+    hipLaunchKernelGGL(k_mspace_out, dim3((total + 255) / 256), dim3(256), 0, stream, ms, M_space, total);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_mspace_grad_in(const float* __restrict__ dM, float* __restrict__ dms, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int n = idx / 2401, r = idx - n * 2401;
+    const int i = r / 49, j = r - i * 49;
+    dms[((size_t)n * 49 + j) * 64 + i] += dM[idx];
+}
+
+hipError_t launch_mspace_grad_in(const float* dM, float* dms, int imgs, hipStream_t stream) {
+    const int total = imgs * 2401;
+    hipLaunchKernelGGL(k_mspace_grad_in, dim3((total + 255) / 256), dim3(256), 0, stream, dM, dms, total);
+    return hipGetLastError();
+}
+
+// ---- CosFace head ------------------------------------------------------------------------------------
+// one wave per row of 512
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_row_normalize(const float* __restrict__ u, int u_pitch, float* __restrict__ v,
+                                                      float* __restrict__ norm, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(u + (size_t)row * u_pitch + lane * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(u + (size_t)row * u_pitch + lane * 8 + 4);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += a[e] * a[e] + b[e] * b[e];
+    s = wave_sum(s);
+    const float d = fmaxf(sqrtf(s), 1e-12f);
+    *reinterpret_cast<f32x4*>(v + (size_t)row * 512 + lane * 8) = a / d;
+    *reinterpret_cast<f32x4*>(v + (size_t)row * 512 + lane * 8 + 4) = b / d;
+    if (lane == 0) norm[row] = d;
+}
+
+hipError_t launch_row_normalize(const float* u, int u_pitch, float* v, float* norm, int rows, hipStream_t stream) {
+    if (u_pitch & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_row_normalize, dim3((rows + 3) / 4), dim3(256), 0, stream, u, u_pitch, v, norm, rows);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_cosface_out(const float* __restrict__ cosv, int cos_pitch,
+                                                    const int* __restrict__ label, float* __restrict__ pred_loss,
+                                                    float* __restrict__ pred_label, int classes, float s, float m) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= classes) return;
+    const float c = cosv[(size_t)n * cos_pitch + k];
+    if (pred_label) pred_label[(size_t)n * classes + k] = c;
+    if (pred_loss) pred_loss[(size_t)n * classes + k] = (k == label[n] ? c - m : c) * s;
+}
+
+hipError_t launch_cosface_out(const float* cosv, int cos_pitch, const int* label, float* pred_loss, float* pred_label,
+                              int imgs, int classes, float s, float m, hipStream_t stream) {
+    hipLaunchKernelGGL(k_cosface_out, dim3((classes + 255) / 256, imgs), dim3(256), 0, stream, cosv, cos_pitch, label,
+                       pred_loss, pred_label, classes, s, m);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_cosface_dcos(const float* __restrict__ dl, const float* __restrict__ dc,
+                                                     float* __restrict__ dcos, int cos_pitch, int classes, float s) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cos_pitch) return;
+    float v = 0.f;
+    if (k < classes) {
+        if (dl) v += s * dl[(size_t)n * classes + k];
+        if (dc) v += dc[(size_t)n * classes + k];
+    }
+    dcos[(size_t)n * cos_pitch + k] = v;
+}
+
+hipError_t launch_cosface_dcos(const float* d_pred_loss, const float* d_pred_label, float* dcos, int cos_pitch, int imgs,
+                               int classes, float s, hipStream_t stream) {
+    hipLaunchKernelGGL(k_cosface_dcos, dim3((cos_pitch + 255) / 256, imgs), dim3(256), 0, stream, d_pred_loss, d_pred_label,
+                       dcos, cos_pitch, classes, s);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_normalize_bwd(const float* __restrict__ dv, int dv_pitch,
+                                                      const float* __restrict__ v, const float* __restrict__ norm,
+                                                      const float* __restrict__ ext, float* __restrict__ du, int du_pitch,
+                                                      int accumulate, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    f32x4 d[2], vv[2];
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        d[q] = *reinterpret_cast<const f32x4*>(dv + (size_t)row * dv_pitch + lane * 8 + 4 * q);
+        vv[q] = *reinterpret_cast<const f32x4*>(v + (size_t)row * 512 + lane * 8 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dot += d[q][e] * vv[q][e];
+    }
+    dot = wave_sum(dot);
+    const float inv = 1.0f / norm[row];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        f32x4 o = (d[q] - vv[q] * dot) * inv;
+        if (ext) o += *reinterpret_cast<const f32x4*>(ext + (size_t)row * 512 + lane * 8 + 4 * q);
+        float* dst = du + (size_t)row * du_pitch + lane * 8 + 4 * q;
+        if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = o;
+    }
+}
+
+hipError_t launch_normalize_bwd(const float* dv, int dv_pitch, const float* v, const float* norm, const float* ext,
+                                float* du, int du_pitch, int accumulate, int rows, hipStream_t stream) {
+    if ((dv_pitch | du_pitch) & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_normalize_bwd, dim3((rows + 3) / 4), dim3(256), 0, stream, dv, dv_pitch, v, norm, ext, du, du_pitch,
+                       accumulate, rows);
+    return hipGetLastError();
+}
+
+// ---- optimiser ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, size_t n4, float lr_bc1, float beta1, float beta2,
+                                             float eps, float weight_decay, float clip, float inv_sqrt_bc2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float ge = fminf(fmaxf(gv[e], -clip), clip);
+        ge += weight_decay * pv[e];
+        mv[e] = mv[e] * beta1 + (1.f - beta1) * ge;
+        vv[e] = vv[e] * beta2 + (1.f - beta2) * ge * ge;
+        const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+        pv[e] -= lr_bc1 * (mv[e] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+}
+
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float clip, int step, hipStream_t stream) {
+    if (n & 3 || step < 1) return hipErrorInvalidValue;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n / 4,
+                       (float)(lr / bc1), beta1, beta2, eps, weight_decay, clip, (float)(1.0 / sqrt(bc2)));
+    return hipGetLastError();
+}
+
+}  // namespace ffr

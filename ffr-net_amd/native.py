@@ -70,6 +70,16 @@ SYMBOLS = [
     ('ffr_recnet_debug', C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     # include/ffrnet_train.h
     ('ffr_op_convlayer_train', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ffr_train_init', C.c_int, [_P, C.POINTER(TensorDesc), C.c_int]),
+    ('ffr_train_info', C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_int)]),
+    ('ffr_train_get', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
+    ('ffr_train_set', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
+    ('ffr_train_zero_grad', C.c_int, [_P, _P]),
+    ('ffr_train_forward', C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ffr_train_backward', C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ffr_train_adam_step', C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    ('ffr_train_debug_copy', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
 ]
 
 
@@ -345,6 +355,88 @@ class Engine(object):
                     dw=dwt, dgamma=dvec[0, :cout], dbeta=dvec[1, :cout], dslope=dvec[2, :cout],
                     running_mean=dvec[3, :cout], running_var=dvec[4, :cout], mean=stats[0, :, :cout],
                     invstd=stats[1, :, :cout])
+
+    # -- RecNet training step (include/ffrnet_train.h) --------------------------------------------
+    N_CLASSES = 10575
+
+    def train_init(self, recnet_state_dict):
+        """Device-resident training state (flat parameter / gradient / Adam buffers) from a RecNet state_dict."""
+        arr, n, keep = self._descs(recnet_state_dict)
+        self._ck(self.lib.ffr_train_init(self._h, arr, n))
+        self._train_spec = {k: tuple(v.shape) for k, v in recnet_state_dict.items()}
+
+    def train_info(self):
+        p, g, n, nbt, step = _P(0), _P(0), C.c_size_t(0), C.c_longlong(0), C.c_int(0)
+        self._ck(self.lib.ffr_train_info(self._h, C.byref(p), C.byref(g), C.byref(n), C.byref(nbt), C.byref(step)))
+        return dict(params=p.value, grads=g.value, n_flat=n.value, num_batches_tracked=nbt.value, adam_step=step.value)
+
+    def train_get(self, key, which='param'):
+        """One tensor in torch layout on the host; which: param | grad | exp_avg | exp_avg_sq | running."""
+        code = {'param': 0, 'grad': 1, 'exp_avg': 2, 'exp_avg_sq': 3, 'running': 4}[which]
+        out = torch.empty(self._train_spec[key], dtype=torch.float32)
+        self._ck(self.lib.ffr_train_get(self._h, code, key.encode(), C.c_void_p(out.data_ptr()), out.numel()))
+        return out
+
+    def train_set(self, key, value, which='param'):
+        code = {'param': 0, 'grad': 1, 'exp_avg': 2, 'exp_avg_sq': 3}[which]
+        v = value.detach().to('cpu', torch.float32).contiguous()
+        self._ck(self.lib.ffr_train_set(self._h, code, key.encode(), C.c_void_p(v.data_ptr()), v.numel()))
+
+    def train_state_dict(self):
+        """The RecNet state_dict as the reference would save it (models/trainer.py:216-224)."""
+        info = self.train_info()
+        sd = {}
+        for k, shape in self._train_spec.items():
+            if k.endswith('num_batches_tracked'):
+                sd[k] = torch.tensor(info['num_batches_tracked'], dtype=torch.long)
+            elif k.endswith(('running_mean', 'running_var')):
+                sd[k] = self.train_get(k, 'running')
+            else:
+                sd[k] = self.train_get(k, 'param')
+        return sd
+
+    def train_zero_grad(self):
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_zero_grad(self._h, self._stream()))
+
+    def train_forward(self, featmap, label, groups=1, slot=0, want=('f_new', 'pred_loss', 'pred_label', 'M_space',
+                                                                      'M_channel', 'feat_space', 'feat_channel')):
+        """RecNet.forward(input, label) in train() mode on `groups` BatchNorm batches stacked along dim 0.
+        Returns the reference's 7-tuple (entries not in `want` are None)."""
+        _check_dev(featmap, 'featmap')
+        featmap = featmap.contiguous()
+        n = featmap.size(0)
+        if featmap.dim() != 4 or tuple(featmap.shape[1:]) != (512, 7, 7) or n % groups:
+            raise RuntimeError('ffrnet_amd: RecNet input must be [G*N,512,7,7], got %s' % list(featmap.shape))
+        lab = label.to(featmap.device, torch.int32).contiguous()
+        dev = featmap.device
+        shapes = dict(f_new=(n, 512), pred_loss=(n, self.N_CLASSES), pred_label=(n, self.N_CLASSES), M_space=(n, 49, 49),
+                      M_channel=(n, 512, 512), feat_space=(n, 512, 7, 7), feat_channel=(n, 512, 7, 7))
+        names = ('f_new', 'pred_loss', 'pred_label', 'M_space', 'M_channel', 'feat_space', 'feat_channel')
+        outs = [torch.empty(shapes[k], device=dev, dtype=torch.float32) if k in want else None for k in names]
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_forward(self._h, slot, _ptr(featmap), _ptr(lab), groups, n // groups,
+                                                *[_ptr(o) for o in outs], self._stream()))
+        return tuple(outs)
+
+    def train_backward(self, grads, slot=0):
+        """grads: 7 tensors or None (gradients wrt the 7-tuple of train_forward); adds into the flat gradient buffer."""
+        gs = [g.contiguous().float() if g is not None else None for g in grads]
+        for g in gs:
+            if g is not None:
+                _check_dev(g, 'grad')
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_backward(self._h, slot, *[_ptr(g) for g in gs], self._stream()))
+
+    def train_debug(self, name, shape, slot=0):
+        out = torch.empty(shape, dtype=torch.float32)
+        self._ck(self.lib.ffr_train_debug_copy(self._h, slot, name.encode(), C.c_void_p(out.data_ptr()), out.numel()))
+        return out
+
+    def train_adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=1.0):
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_adam_step(self._h, lr, betas[0], betas[1], eps, weight_decay, clip_value,
+                                                  self._stream()))
 
     def encoder_trunk_nhwc(self, x, n_blocks):
         _check_dev(x, 'x')

@@ -33,6 +33,59 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
                            const float* slope_host, const float* da_nhwc, float* out_nhwc, float* dx_nhwc,
                            float* dw_packed, float* dvec, float* stats, void* stream);
 
+/* ---- the training state of one handle -----------------------------------------------------------------
+ * ffr_train_init: takes the RecNet state_dict (the 121 entries of the reference's RecNet incl.
+ * classifier.weight and the BatchNorm running statistics; host fp32 pointers as for ffr_load_recnet;
+ * num_batches_tracked is not needed) and builds the device-resident training state: ONE flat fp32
+ * parameter buffer in kernel layouts (conv weights [cout_pad][9][cin_pad], vectors padded to 64, linear
+ * weights [out_pad][in_pad]), an equally laid out gradient buffer and the two Adam moment buffers
+ * (torch.optim.Adam state, models/trainer.py:120), all zero.  Replaces RecNet.__init__ / .to(device) /
+ * optim.Adam(...) of models/trainer.py:60,71,115-121 for the native path.                             */
+int ffr_train_init(ffr_handle* h, const ffr_tensor_desc* recnet_state_dict, int n);
+
+/* device pointers of the flat parameter / gradient buffers (n_flat floats each: the message of the
+ * data-parallel gradient all-reduce that replaces nn.parallel.data_parallel, models/trainer.py:70-72),
+ * the number of BatchNorm updates since init (num_batches_tracked increment) and Adam's step count.  */
+int ffr_train_info(ffr_handle* h, float** params, float** grads, size_t* n_flat,
+                   long long* num_batches_tracked, int* adam_step);
+
+/* one tensor in the reference's (torch) layout to / from host memory; `which`: 0 parameter, 1 gradient,
+ * 2 exp_avg, 3 exp_avg_sq, 4 BatchNorm running statistic (get only).  n = number of elements of the
+ * state_dict entry `key`.  Synchronises the device.  (state_dict() / load_state_dict(), trainer.py:201-224) */
+int ffr_train_get(ffr_handle* h, int which, const char* key, float* host_out, size_t n);
+int ffr_train_set(ffr_handle* h, int which, const char* key, const float* host_in, size_t n);
+
+/* optimizer.zero_grad() (models/trainer.py:184) */
+int ffr_train_zero_grad(ffr_handle* h, void* stream);
+
+/* RecNet.forward(input, label) in train() mode (models/recnet.py:398-429) on G groups of N images; every
+ * group is its own BatchNorm batch (the reference calls RecNet once per group, trainer.py:144-145) and
+ * updates the running statistics in group order.  featmap_nchw [G*N,512,7,7], label int32 [G*N] (device).
+ * Outputs (device, any may be NULL), as the reference's 7-tuple: f_new [G*N,512], pred_loss and pred_label
+ * [G*N,10575], M_space [G*N,49,49], M_channel [G*N,512,512], feat_space, feat_channel [G*N,512,7,7].
+ * The activations needed by the backward are kept in context `slot` (0 or 1) until ffr_train_backward. */
+int ffr_train_forward(ffr_handle* h, int slot, const float* featmap_nchw, const int32_t* label, int G, int N,
+                      float* f_new, float* pred_loss, float* pred_label, float* M_space, float* M_channel,
+                      float* feat_space, float* feat_channel, void* stream);
+
+/* backward of the forward recorded in `slot`, given the gradients of a scalar loss with respect to the
+ * seven outputs (same shapes, device, any may be NULL = zero); ADDS the parameter gradients to the flat
+ * gradient buffer (autograd semantics of loss.backward(), models/trainer.py:179-180).  No gradient with
+ * respect to the input feature map is produced: the encoder is frozen (models/trainer.py:62-63).     */
+int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const float* d_pred_loss,
+                       const float* d_pred_label, const float* d_M_space, const float* d_M_channel,
+                       const float* d_feat_space, const float* d_feat_channel, void* stream);
+
+/* clip_grad_value_(clip_value) (<= 0: no clipping) followed by one torch.optim.Adam step on every
+ * parameter (models/trainer.py:182-187); one fused elementwise launch over the flat buffers.           */
+int ffr_train_adam_step(ffr_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        float clip_value, void* stream);
+
+/* Test hook: the first n floats of a named intermediate buffer of context `slot` (forward activations:
+ * "X" "cat" "h1pre" "h1" "t2" "h2pre" "h3pre" "Mc" "raw" "Xht"; backward scratch: "d32a" "d32b" "dMc" "dt"
+ * "dBufM" "dF" "dms") copied to host memory, in the kernel layouts.  Synchronises the device.          */
+int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

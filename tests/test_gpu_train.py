@@ -64,3 +64,109 @@ def test_convlayer_train_forward_backward(engine, case):
     assert rel(res['dgamma'], gr.grad) < GRAD_TOL
     assert rel(res['dbeta'], br.grad) < GRAD_TOL
     assert rel(res['dslope'], sr.grad) < GRAD_TOL
+
+
+# ---- the whole RecNet training step ---------------------------------------------------------------
+@pytest.fixture(scope='module')
+def train_case(specs):
+    return build_train_case(specs)
+
+
+def build_train_case(specs):
+    """The G8 scenario (4 clean + 4 occluded images, synthetic weights) through the ORACLE with autograd:
+    outputs, gradients wrt the seven outputs of both RecNet calls, parameter gradients (unclipped)."""
+    import ffr_oracle as O
+    import ffr_oracle_train as OT
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    non, ocl, label = synth.synth_train_batch(4, seed=301)
+    with torch.no_grad():
+        fm_non, fe_non = O.encoder_forward(sd_e, non)
+        fm_ocl, fe_ocl = O.encoder_forward(sd_e, ocl)
+    keys = OT.trainable_keys(sd_r)
+    params = {k: sd_r[k].clone().requires_grad_(True) for k in keys}
+    running = {k: v.clone() for k, v in sd_r.items() if k not in params}
+    out_non = OT.recnet_train_forward(params, fm_non, label, running)
+    out_ocl = OT.recnet_train_forward(params, fm_ocl, label, running)
+    items = OT.trainer_losses(out_non, out_ocl, fm_non, fe_non, fe_ocl, label)
+    grads = torch.autograd.grad(sum(items), [params[k] for k in keys], allow_unused=True)
+    pg = {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(keys, grads)}
+    # cotangents of the 7-tuples: the PARTIAL derivatives of the loss, outputs taken as independent leaves
+    # (pred_loss is a function of pred_label, f_new of feat_space ... inside the graph)
+    leaf_non = [o.detach().clone().requires_grad_(True) for o in out_non]
+    leaf_ocl = [o.detach().clone().requires_grad_(True) for o in out_ocl]
+    items_l = OT.trainer_losses(leaf_non, leaf_ocl, fm_non, fe_non, fe_ocl, label)
+    og = torch.autograd.grad(sum(items_l), leaf_non + leaf_ocl, allow_unused=True)
+    return dict(sd_r=sd_r, fm=torch.cat([fm_non, fm_ocl]), label=torch.cat([label, label]), out_non=out_non,
+                out_ocl=out_ocl, out_grads=og, param_grads=pg, running=running, keys=keys,
+                losses=[float(l.detach()) for l in items])
+
+
+NAMES = ['f_new', 'pred_loss', 'pred_label', 'M_space', 'M_channel', 'feat_space', 'feat_channel']
+
+
+def test_train_forward_matches_oracle_and_golden(engine, train_case, golden_dir):
+    """RecNet.forward(input, label) in train() mode (models/recnet.py:398-429), both groups in one call."""
+    tc = train_case
+    engine.train_init(tc['sd_r'])
+    outs = engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2)
+    torch.cuda.synchronize()
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    for gi, (tag, ref) in enumerate((('non', tc['out_non']), ('ocl', tc['out_ocl']))):
+        for nm, o, r in zip(NAMES, outs, ref):
+            got = o[gi * 4:(gi + 1) * 4].cpu()
+            r = r.detach().reshape(got.shape)
+            assert rel(got, r) < 1e-4, (tag, nm, rel(got, r))
+        assert rel(outs[0][gi * 4:(gi + 1) * 4], torch.from_numpy(g8['full.%s.f' % tag])) < 1e-4
+        assert rel(outs[3][gi * 4], torch.from_numpy(g8['full.%s.M_space0' % tag]).reshape(49, 49)) < 1e-4
+        assert rel(outs[6][gi * 4], torch.from_numpy(g8['full.%s.feat_channel0' % tag])) < 1e-4
+    sd_after = engine.train_state_dict()
+    for k, v in tc['running'].items():
+        if k.endswith(('running_mean', 'running_var')):
+            assert rel(sd_after[k], v) < 1e-4, k
+            assert rel(sd_after[k], torch.from_numpy(g8['after.' + k]).float()) < 1e-4, k
+        elif k.endswith('num_batches_tracked'):
+            assert int(sd_after[k]) == 2
+
+
+def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir):
+    """loss.backward() through RecNet (models/trainer.py:179-180): parameter gradients for the reference's
+    four losses, cotangents of the 7-tuple taken from the oracle's autograd."""
+    tc = train_case
+    engine.train_init(tc['sd_r'])
+    engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
+    og = tc['out_grads']
+    stacked = []
+    for i in range(7):
+        a, b = og[i], og[7 + i]
+        if a is None and b is None:
+            stacked.append(None)
+            continue
+        ref_shape = tc['out_non'][i].shape
+        a = a if a is not None else torch.zeros(ref_shape)
+        b = b if b is not None else torch.zeros(ref_shape)
+        stacked.append(torch.cat([a, b]).cuda())
+    engine.train_zero_grad()
+    engine.train_backward(stacked)
+    torch.cuda.synchronize()
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    worst = ('', 0.0)
+    # One pre-activation of the first Conv4Channel PReLU is 2.2e-8 in this scenario (|h1pre| max 5.8): the
+    # GPU and the CPU round it to opposite sides of the PReLU kink, which moves that element's gradient by
+    # 1 - slope (tools/train_grad_report.py prints the flip).  Only the first linear sees it undiluted.
+    kink = {'Conv4Channel.0.weight': 5e-3, 'Conv4Channel.0.bias': 5e-3}
+    for k in tc['keys']:
+        got = engine.train_get(k, 'grad')
+        ref = tc['param_grads'][k]
+        e = rel(got, ref) if ref.abs().max() > 0 else got.abs().max().item()
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < kink.get(k, 1e-4), (k, e)
+        # the reference's own (clipped) gradients: digest = [sum, abs-sum, 64 strided samples]
+        d = g8['grad.' + k]
+        c = got.clamp(-1.0, 1.0)
+        f = c.reshape(-1)
+        samples = f[::max(1, f.numel() // 64)][:64].double()
+        assert rel(samples, torch.from_numpy(d[2:])) < kink.get(k, 1e-4), k
+        assert abs(c.double().abs().sum().item() - d[1]) <= kink.get(k, 1e-4) * max(d[1], 1e-12), k
+    print('worst gradient error', worst)
