@@ -10,6 +10,8 @@ from .native import Engine, GraphedEmbed, NativeLibraryMissing, lib_path  # noqa
 from .modules import Backbone, RecNet, ir_se_50_512, l2_norm  # noqa: F401
 from . import lfw  # noqa: F401
 from . import checkpoint  # noqa: F401
+from . import train  # noqa: F401
+from .train import NativeTrainer  # noqa: F401
 
 __all__ = ['Backbone', 'RecNet', 'ir_se_50_512', 'l2_norm', 'Engine', 'GraphedEmbed',
-           'NativeLibraryMissing', 'lib_path', 'synth', 'lfw', 'checkpoint']
+           'NativeLibraryMissing', 'lib_path', 'synth', 'lfw', 'checkpoint', 'train', 'NativeTrainer']

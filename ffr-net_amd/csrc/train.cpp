@@ -754,13 +754,13 @@ int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const floa
     return FFR_OK;
 }
 
-int ffr_train_adam_step(ffr_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value,
-                        void* stream) {
+int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        double clip_value, void* stream) {
     TrainState* t;
     RC(get_train(h, &t));
     t->adam_step += 1;
     HIPCK(h, launch_adam(t->P, t->Gr, t->M1, t->M2, t->n_flat, lr, beta1, beta2, eps, weight_decay,
-                         clip_value > 0.f ? clip_value : 3.0e38f, t->adam_step, (hipStream_t)stream));
+                         clip_value > 0.0 ? (float)clip_value : 3.0e38f, t->adam_step, (hipStream_t)stream));
     return FFR_OK;
 }
 

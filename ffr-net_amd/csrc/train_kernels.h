@@ -109,7 +109,7 @@ hipError_t launch_normalize_bwd(const float* dv, int dv_pitch, const float* v, c
 
 // ---- optimiser (models/trainer.py:115-121,182-187) -----------------------------------------------------
 // clip_grad_value_(clip) then torch.optim.Adam: p, g, m, v flat arrays of n floats; step counts from 1
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, float clip, int step, hipStream_t stream);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, float clip, int step, hipStream_t stream);
 
 }  // namespace ffr

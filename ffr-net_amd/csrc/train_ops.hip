@@ -731,7 +731,8 @@ hipError_t launch_normalize_bwd(const float* dv, int dv_pitch, const float* v, c
 // ---- optimiser ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, size_t n4, float lr_bc1, float beta1, float beta2,
-                                             float eps, float weight_decay, float clip, float inv_sqrt_bc2) {
+                                             float omb1, float omb2, float eps, float weight_decay, float clip,
+                                             float inv_sqrt_bc2) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
@@ -740,8 +741,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     for (int e = 0; e < 4; ++e) {
         float ge = fminf(fmaxf(gv[e], -clip), clip);
         ge += weight_decay * pv[e];
-        mv[e] = mv[e] * beta1 + (1.f - beta1) * ge;
-        vv[e] = vv[e] * beta2 + (1.f - beta2) * ge * ge;
+        mv[e] = mv[e] * beta1 + omb1 * ge;
+        vv[e] = vv[e] * beta2 + omb2 * ge * ge;
         const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
         pv[e] -= lr_bc1 * (mv[e] / denom);
     }
@@ -750,12 +751,14 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     reinterpret_cast<f32x4*>(v)[i] = vv;
 }
 
-hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                       float eps, float weight_decay, float clip, int step, hipStream_t stream) {
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, float clip, int step, hipStream_t stream) {
     if (n & 3 || step < 1) return hipErrorInvalidValue;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    // scalars in double on the host as torch.optim.Adam does (1 - beta2 = 1e-3 is not exact in fp32)
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n / 4,
-                       (float)(lr / bc1), beta1, beta2, eps, weight_decay, clip, (float)(1.0 / sqrt(bc2)));
+                       (float)(lr / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                       (float)weight_decay, clip, (float)(1.0 / sqrt(bc2)));
     return hipGetLastError();
 }
 

@@ -78,7 +78,7 @@ SYMBOLS = [
     ('ffr_train_zero_grad', C.c_int, [_P, _P]),
     ('ffr_train_forward', C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     ('ffr_train_backward', C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    ('ffr_train_adam_step', C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    ('ffr_train_adam_step', C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     ('ffr_train_debug_copy', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
 ]
 

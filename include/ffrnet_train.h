@@ -78,8 +78,8 @@ int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const floa
 
 /* clip_grad_value_(clip_value) (<= 0: no clipping) followed by one torch.optim.Adam step on every
  * parameter (models/trainer.py:182-187); one fused elementwise launch over the flat buffers.           */
-int ffr_train_adam_step(ffr_handle* h, float lr, float beta1, float beta2, float eps, float weight_decay,
-                        float clip_value, void* stream);
+int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        double clip_value, void* stream);
 
 /* Test hook: the first n floats of a named intermediate buffer of context `slot` (forward activations:
  * "X" "cat" "h1pre" "h1" "t2" "h2pre" "h3pre" "Mc" "raw" "Xht"; backward scratch: "d32a" "d32b" "dMc" "dt"

@@ -170,3 +170,76 @@ def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir
         assert rel(samples, torch.from_numpy(d[2:])) < kink.get(k, 1e-4), k
         assert abs(c.double().abs().sum().item() - d[1]) <= kink.get(k, 1e-4) * max(d[1], 1e-12), k
     print('worst gradient error', worst)
+
+
+def test_adam_and_clip_match_torch(engine, specs):
+    """clip_grad_value_(1.0) + torch.optim.Adam (models/trainer.py:120,182-187): three steps with given gradients."""
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    engine.train_init(sd_r)
+    keys = ['Conv4Space.4.conv2d.weight', 'Conv4Channel.0.weight', 'Conv4Space.5.conv2.norm.norm.bias',
+            'Conv4Channel.7.func.weight']
+    params = [sd_r[k].clone().requires_grad_(True) for k in keys]
+    opt = torch.optim.Adam(params, 0.1, betas=(0.9, 0.999), weight_decay=0)
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        engine.train_zero_grad()
+        for k, p in zip(keys, params):
+            grad = torch.randn(p.shape, generator=g) * (3.0 if step == 1 else 0.3)     # some beyond the clip value
+            engine.train_set(k, grad, 'grad')
+            p.grad = grad.clone()
+        torch.nn.utils.clip_grad_value_(params, 1.0)
+        opt.step()
+        engine.train_adam_step(0.1, (0.9, 0.999), 1e-8, 0.0, 1.0)
+    torch.cuda.synchronize()
+    for k, p in zip(keys, params):
+        assert rel(engine.train_get(k, 'param'), p) < 1e-5, k
+        assert rel(engine.train_get(k, 'exp_avg'), opt.state[p]['exp_avg']) < 1e-5, k
+        assert rel(engine.train_get(k, 'exp_avg_sq'), opt.state[p]['exp_avg_sq']) < 1e-5, k
+    # untouched parameters (zero gradient) do not move
+    assert torch.equal(engine.train_get('Conv4Merge.0.conv2d.weight', 'param'), sd_r['Conv4Merge.0.conv2d.weight'])
+    assert engine.train_info()['adam_step'] == 3
+
+
+def test_native_trainer_step_matches_reference(specs, golden_dir):
+    """One whole iteration (train.py:46-54) through NativeTrainer vs the golden captured from the reference's
+    Trainer: the four loss items, the accuracy, clipped gradients, running statistics, updated parameters."""
+    import ffr_oracle_train as OT
+    g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    non, ocl, label = synth.synth_train_batch(4, seed=301)
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
+    items = tr.step(non.cuda(), ocl.cuda(), label.cuda())
+    torch.cuda.synchronize()
+    got = np.array([float(l) for l in items])
+    assert np.allclose(got, g8['losses'], rtol=1e-4), (got, g8['losses'])
+    assert float(tr.accuracy) == float(g8['accuracy'])
+    sd_after = tr.state_dict()
+    for k in sd_after:
+        if k.endswith(('running_mean', 'running_var')):
+            assert rel(sd_after[k], torch.from_numpy(g8['after.' + k]).float()) < 1e-4, k
+    # The parameter gradients of this 8-image batch move by percents when the feature map moves by 1e-5 (the GPU
+    # encoder's rounding): pre-activations cross PReLU kinks and the per-channel sums over 392 rows cancel
+    # heavily.  So the gradients are held to the oracle evaluated ON THE GPU's feature maps (same inputs, the
+    # remaining differences are rounding only), in relative L2 per tensor.
+    import ffr_oracle as O
+    fm, f_enc = eng.encoder_forward(torch.cat((non, ocl)).cuda())
+    fm, f_enc = fm.cpu(), f_enc.cpu()
+    keys = OT.trainable_keys(sd_r)
+    params = {k: sd_r[k].clone().requires_grad_(True) for k in keys}
+    running = {k: v.clone() for k, v in sd_r.items() if k not in params}
+    out_non = OT.recnet_train_forward(params, fm[:4], label, running)
+    out_ocl = OT.recnet_train_forward(params, fm[4:], label, running)
+    ref_items = OT.trainer_losses(out_non, out_ocl, fm[:4], f_enc[:4], f_enc[4:], label)
+    ref_grads = torch.autograd.grad(sum(ref_items), [params[k] for k in keys])
+    for k, rg in zip(keys, ref_grads):
+        got_g = eng.train_get(k, 'grad')
+        l2 = ((got_g - rg).norm() / rg.norm().clamp_min(1e-30)).item()
+        assert l2 < 5e-3, (k, l2)
+        # the optimiser inside the step: Adam's first update of the clipped native gradient, torch's formula
+        gc = got_g.clamp(-1.0, 1.0)
+        m, v = 0.1 * gc, 0.001 * gc * gc
+        expect = sd_r[k] - (0.1 / 0.1) * m / ((v.sqrt() / (1.0 - 0.999) ** 0.5) + 1e-8)
+        assert (sd_after[k] - expect).abs().max().item() < 2e-5, k

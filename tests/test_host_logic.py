@@ -170,3 +170,32 @@ def test_checkpoint_containers_round_trip(tmp_path, specs):
     del w['RecNet']['classifier.weight']
     ck.save(w, str(tmp_path / 'noclf.pth.gzip'))
     ck.load_recnet_checkpoint(ffrnet_amd.RecNet(), str(tmp_path / 'noclf.pth.gzip'))
+
+
+def _avg_grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ffrnet_amd import train
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    train.average_gradients(flat)
+    q.put((rank, flat[:4].tolist(), float(flat.sum())))
+    dist.destroy_process_group()
+
+
+def test_gradient_averaging_two_ranks():
+    """The data-parallel exchange of the training step: one all-reduce of the flat gradient buffer, mean over ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_avg_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, head, total in res:
+        assert head == [0.0, 1.5, 3.0, 4.5]
+        assert abs(total - 1.5 * 999 * 1000 / 2) < 1e-3
