@@ -299,7 +299,7 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
     const size_t imgs = imgs_i, rows = imgs * 49, crow = imgs * 512;
     auto carve = [&](char* base) -> size_t {
         Arena a(base, 0);
-        size_t partd = bn_part_doubles(1, (int)(rows > crow ? rows : crow), 1536);
+        const size_t partd = (size_t)1 << 20;    // >= G * 32 slices * 3 sums * 1536 channels and >= 512 slices * 512 columns
         t->sc.part = (double*)a.take(partd * 2);
         t->sc.wd_floats = (size_t)1536 * 9 * 512; t->sc.wd = a.take(t->sc.wd_floats);
         t->sc.dxp_floats = imgs * 81 * 1024; t->sc.dxp = a.take(t->sc.dxp_floats);

@@ -64,7 +64,7 @@ hipError_t launch_avgpool_bwd(const float* df, const float* add, float* out, int
 hipError_t launch_fill(float* p, float v, size_t n, hipStream_t stream);
 // g = (g + ext) * s * (1 - s) on compact [n] arrays (ext may be null)
 hipError_t launch_sigmoid_bwd_ext(float* g, const float* ext, const float* s, size_t n, hipStream_t stream);
-// out[c] (+)= sum_rows x[row][c]; part: scratch of bn_part_doubles(1, rows, Cp) doubles; Cp % 64 == 0
+// out[c] (+)= sum_rows x[row][c]; part: scratch of 512 * Cp doubles; Cp % 64 == 0
 hipError_t launch_colsum(const float* x, int pitch, int rows, int Cp, float* out, int accumulate, double* part,
                          hipStream_t stream);
 // Wt[c][r] = W[r][c] for r < R, c < C; Wt is [Cp][Rp], zero elsewhere

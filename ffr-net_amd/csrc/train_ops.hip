@@ -9,13 +9,16 @@ namespace ffr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static const int SLICE_ROWS = 98;
-
-static int n_slices(int rows_g) { return (rows_g + SLICE_ROWS - 1) / SLICE_ROWS; }
+// rows are cut into at most 32 slices per group (the *_final kernels walk the slices serially per channel)
+static int n_slices(int rows_g) {
+    const int n = (rows_g + 97) / 98;
+    return n > 32 ? 32 : n;
+}
+static int slice_rows(int rows_g) { const int n = n_slices(rows_g); return (rows_g + n - 1) / n; }
 size_t bn_part_doubles(int G, int rows_g, int Cp) { return (size_t)G * n_slices(rows_g) * 3 * Cp; }
 
 // grid (Cp/64, nslices, G), block 256 = 64 channels x 4 row lanes
-__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ y, int Cp, int rows_g,
+__global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restrict__ y, int Cp, int rows_g, int SLICE_ROWS,
                                                          double* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int s = blockIdx.y, g = blockIdx.z, nsl = gridDim.y;
@@ -77,7 +80,7 @@ hipError_t launch_bn_stats(const float* y, int Cp, int G, int rows_g, const floa
                            double* part, hipStream_t stream) {
     if (Cp % 64 || G <= 0 || rows_g <= 0) return hipErrorInvalidValue;
     const int nsl = n_slices(rows_g);
-    hipLaunchKernelGGL(k_bn_stats_partial, dim3(Cp / 64, nsl, G), dim3(256), 0, stream, y, Cp, rows_g, part);
+    hipLaunchKernelGGL(k_bn_stats_partial, dim3(Cp / 64, nsl, G), dim3(256), 0, stream, y, Cp, rows_g, slice_rows(rows_g), part);
     hipLaunchKernelGGL(k_bn_stats_final, dim3(Cp / 64), dim3(64), 0, stream, part, Cp, G, nsl, rows_g, gamma, beta,
                        running_mean, running_var, momentum, eps, b);
     return hipGetLastError();
@@ -125,8 +128,9 @@ hipError_t launch_bn_apply(const float* y, int Cp, int G, int rows_g, BnBuffers 
 // z = y*scale + shift; dz = da * (z > 0 ? 1 : slope); xhat = (y - mean)*invstd
 // sums per group/channel: S1 = sum dz, S2 = sum dz*xhat, S3 = sum da * min(z, 0)  (-> dslope)
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ da, int da_pitch, int da_coff,
-                                                       const float* __restrict__ y, int Cp, int rows_g, BnBuffers b,
-                                                       const float* __restrict__ slope, double* __restrict__ part) {
+                                                       const float* __restrict__ y, int Cp, int rows_g, int SLICE_ROWS,
+                                                       BnBuffers b, const float* __restrict__ slope,
+                                                       double* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int s = blockIdx.y, g = blockIdx.z, nsl = gridDim.y;
     const int r0 = s * SLICE_ROWS;
@@ -209,7 +213,7 @@ hipError_t launch_bn_bwd(const float* da, int da_pitch, int da_coff, const float
     if (Cp % 64 || ((da_pitch | da_coff) & 3)) return hipErrorInvalidValue;
     const int nsl = n_slices(rows_g);
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(Cp / 64, nsl, G), dim3(256), 0, stream, da, da_pitch, da_coff, y, Cp, rows_g,
-                       b, slope, part);
+                       slice_rows(rows_g), b, slope, part);
     hipLaunchKernelGGL(k_bn_bwd_final, dim3(Cp / 64), dim3(64), 0, stream, part, Cp, G, nsl, rows_g, b, dgamma, dbeta,
                        dslope, accumulate);
     const long long total4 = (long long)G * rows_g * (Cp >> 2);
@@ -376,7 +380,7 @@ hipError_t launch_sigmoid_bwd_ext(float* g, const float* ext, const float* s, si
 }
 
 __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int pitch, int rows, int Cp,
-                                                       double* __restrict__ part) {
+                                                       int SLICE_ROWS, double* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
     const int s = blockIdx.y;
     const int r0 = s * SLICE_ROWS;
@@ -392,22 +396,31 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void k_colsum_final(const double* __restrict__ part, int Cp, int nsl, float* out,
-                                                    int accumulate) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= Cp) return;
+// 64 channels x 4 slice lanes per block
+__global__ __launch_bounds__(256) void k_colsum_final(const double* __restrict__ part, int Cp, int nsl, float* out,
+                                                     int accumulate) {
+    const int t = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + t;
     double a = 0.0;
-    for (int s = 0; s < nsl; ++s) a += part[(size_t)s * Cp + c];
-    if (accumulate) a += out[c];
-    out[c] = (float)a;
+    for (int s = sl; s < nsl; s += 4) a += part[(size_t)s * Cp + c];
+    __shared__ double sh[4][64];
+    sh[sl][t] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        a = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+        if (accumulate) a += out[c];
+        out[c] = (float)a;
+    }
 }
 
 hipError_t launch_colsum(const float* x, int pitch, int rows, int Cp, float* out, int accumulate, double* part,
                          hipStream_t stream) {
     if (Cp % 64) return hipErrorInvalidValue;
-    const int nsl = n_slices(rows);
-    hipLaunchKernelGGL(k_colsum_partial, dim3(Cp / 64, nsl), dim3(256), 0, stream, x, pitch, rows, Cp, part);
-    hipLaunchKernelGGL(k_colsum_final, dim3(Cp / 64), dim3(64), 0, stream, part, Cp, nsl, out, accumulate);
+    int nsl = (rows + 97) / 98;            // up to 512 slices: tall, narrow inputs (131072 x 64) need the blocks
+    if (nsl > 512) nsl = 512;
+    const int sr = (rows + nsl - 1) / nsl;
+    hipLaunchKernelGGL(k_colsum_partial, dim3(Cp / 64, nsl), dim3(256), 0, stream, x, pitch, rows, Cp, sr, part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(Cp / 64), dim3(256), 0, stream, part, Cp, nsl, out, accumulate);
     return hipGetLastError();
 }
 

@@ -1,0 +1,65 @@
+"""Training-step timing (BASELINE.json configs[4] shape: 128 image pairs per GPU): phases of NativeTrainer.step
+timed with HIP events on the launch stream.  Secondary measurement -- bench.py stays the headline metric.
+    python tools/bench_train.py [--batch 128] [--steps 10] [--warmup 3]
+"""
+import argparse, json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ffrnet_amd
+from ffrnet_amd import synth, train
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    a = ap.parse_args()
+    specs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g0_state_dict_keys.json')))
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(synth.synth_state_dict(specs['encoder'], seed=0))
+    tr = ffrnet_amd.NativeTrainer(eng, synth.synth_state_dict(specs['recnet'], seed=0), lr=1e-3)
+    non, ocl, label = synth.synth_train_batch(a.batch, seed=11)
+    non, ocl, label = non.cuda(), ocl.cuda(), label.cuda()
+    n = a.batch
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    phases = ['encoder', 'recnet_fwd', 'losses', 'recnet_bwd', 'adam']
+    tot = {p: 0.0 for p in phases}
+    wall = 0.0
+    for it in range(a.warmup + a.steps):
+        e = [ev() for _ in range(6)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e[0].record()
+        with torch.no_grad():
+            fm, f_enc = eng.encoder_forward(torch.cat((non, ocl), 0))
+        e[1].record()
+        lab2 = torch.cat((label, label))
+        outs = eng.train_forward(fm, lab2, groups=2, want=('f_new', 'pred_loss', 'pred_label', 'feat_space', 'feat_channel'))
+        e[2].record()
+        f_new, pred_loss, pred_label, _, _, feat_space, feat_channel = outs
+        lf, lp, ls, lc = [t.detach().requires_grad_(True) for t in (f_new, pred_loss, feat_space, feat_channel)]
+        items = train.trainer_losses(lf[:n], lf[n:], lp[:n], lp[n:], ls[:n], ls[n:], lc[:n], lc[n:], fm[:n], f_enc[:n],
+                                     f_enc[n:], label.long())
+        torch.autograd.backward(sum(items))
+        e[3].record()
+        eng.train_zero_grad()
+        eng.train_backward([lf.grad, lp.grad, None, None, None, ls.grad, lc.grad])
+        e[4].record()
+        eng.train_adam_step(1e-3, (0.9, 0.999), 1e-8, 0.0, 1.0)
+        e[5].record()
+        torch.cuda.synchronize()
+        if it >= a.warmup:
+            wall += time.perf_counter() - t0
+            for i, p in enumerate(phases):
+                tot[p] += e[i].elapsed_time(e[i + 1])
+    ms = {p: round(v / a.steps, 3) for p, v in tot.items()}
+    step_ms = wall / a.steps * 1e3
+    print(json.dumps({'metric': 'RecNet training iterations/s (encoder frozen; clean+occluded pairs)', 'batch_pairs_per_gpu': n,
+                      'ms_per_step': round(step_ms, 3), 'pairs_per_s': round(n / step_ms * 1e3, 1), 'phase_ms': ms,
+                      'losses': [round(float(l), 5) for l in items]}))
+
+
+if __name__ == '__main__':
+    main()
