@@ -385,6 +385,7 @@ Work layout(char* base, int N, int H, int W) {
         if (36 * tiles(4) * 256 > cap) cap = 36 * tiles(4) * 256;           // 28x28, 128 -> 256
         if (36 * tiles(8) * 512 > cap) cap = 36 * tiles(8) * 512;           // 14x14, 256 -> 512
         if (36 * tiles(16) * 1536 > cap) cap = 36 * tiles(16) * 1536;       // 7x7, RecNet 1536 -> 512
+        if (36 * (size_t)N * 9 * 1024 > cap) cap = 36 * (size_t)N * 9 * 1024;  // 9x9 data gradient of the training step, 1024 channels
         w.wino_cap = cap;
         w.winoV = a.take(cap);
         w.winoM = a.take(cap);

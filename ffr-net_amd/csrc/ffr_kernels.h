@@ -52,6 +52,8 @@ hipError_t launch_gemm_stream(GemmStreamArgs a, int tile, int nblocks, hipStream
 // V[36][T][cin_pad] = B^T d B of every 6x6 patch (T = N*ceil(H/4)*ceil(W/4)); pad 1, stride 1
 hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
                           hipStream_t stream);
+// U[36][out_pad][in_pad] = G g G^T of W[out_pad][9][in_pad] (device-side; the training step re-derives it per step)
+hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream);
 // out = epilogue(A^T M A): bias[(border class)][cout_pad], PReLU, residual, sigmoid (flags bit0)
 hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
                            float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,

@@ -35,24 +35,35 @@ struct TScratch {
     float* dxp = nullptr; size_t dxp_floats = 0;   // 9x9 padded data gradient
     float* dy = nullptr; size_t dy_floats = 0;     // gradient wrt the raw convolution output
     float* slabs = nullptr; size_t slab_floats = 0;  // split-K slabs of the weight gradient
+    float* U = nullptr; size_t U_floats = 0;         // Winograd weights of the layer at hand (re-derived per use)
+    float* canvas = nullptr; size_t canvas_floats = 0;   // dy embedded in a 9x9 zero-bordered map
+    bool wino = !(getenv("FFR_TRAIN_WINO") && atoi(getenv("FFR_TRAIN_WINO")) == 0);   // ffr_train_option("winograd")
 };
 
-void conv_call_common(ConvCall& c, const Work& w) {
+void conv_call_common(ConvCall& c, const Work& w, bool wino = false) {
     c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
-    c.winoV = nullptr; c.winoM = nullptr; c.wino_cap = 0; c.wino_mode = 0;
+    c.winoV = wino ? w.winoV : nullptr; c.winoM = wino ? w.winoM : nullptr; c.wino_cap = wino ? w.wino_cap : 0;
+    c.wino_mode = wino ? 1 : 0;
 }
 
 // y = conv(reflect_pad(x)); batch statistics; out = PReLU(BN(y)) (+ resid) (sigmoid when flags & 1)
 int layer_forward(ffr_handle* h, const Work& w, const TLayer& L, TSaved& sv, int G, int N, const float* resid,
-                  int res_pitch, float* out, int out_pitch, int out_coff, int flags, bool update_running, double* part,
+                  int res_pitch, float* out, int out_pitch, int out_coff, int flags, bool update_running, TScratch& s,
                   hipStream_t st) {
+    double* part = s.part;
     ConvW cw;
     cw.cin = L.cin; cw.cin_pad = L.cin_pad; cw.cout = L.cout; cw.cout_pad = L.cout_pad; cw.R = 3; cw.S = 3; cw.stride = 1;
     cw.pad = 1; cw.pad_mode = 1; cw.border = 0; cw.w = L.w; cw.bias = h->zero; cw.slope = nullptr; cw.wu = nullptr;
+    // Winograd F(4x4,3x3) as the inference path (section 3.2 of DESIGN.md); U = G g G^T from the live weights
+    const bool wino = s.wino && L.cin_pad >= 128 && s.U && (size_t)36 * L.cout_pad * L.cin_pad <= s.U_floats;
+    if (wino) {
+        HIPCK(h, launch_wino_weights(L.w, s.U, L.cout_pad, L.cin_pad, st));
+        cw.wu = s.U;
+    }
     ConvCall c{};
     c.x = sv.x; c.N = G * N; c.H = 7; c.W = 7; c.in_pitch = sv.x_pitch;
     c.out = sv.y; c.out_pitch = L.cout_pad; c.out_coff = 0; c.cout_store = L.cout_pad;
-    conv_call_common(c, w);
+    conv_call_common(c, w, wino);
     RC(run_conv(h, cw, c, st));
     HIPCK(h, launch_bn_stats(sv.y, L.cout_pad, G, N * 49, L.gamma, L.beta, update_running ? L.rmean : nullptr,
                              update_running ? L.rvar : nullptr, BN_MOMENTUM, BN_EPS_F, sv.bn, part, st));
@@ -84,7 +95,16 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
     ConvCall c{};
     c.x = s.dy; c.N = G * N; c.H = 7; c.W = 7; c.in_pitch = L.cout_pad;
     c.out = s.dxp; c.out_pitch = need_pad; c.out_coff = 0; c.cout_store = need_pad;
-    conv_call_common(c, w);
+    const bool wino = s.wino && L.cout_pad >= 128 && s.U && (size_t)36 * need_pad * L.cout_pad <= s.U_floats &&
+                      (size_t)G * N * 81 * L.cout_pad <= s.canvas_floats;
+    if (wino) {
+        // the same 9x9 result as a 'same' convolution of dy embedded in a zero-bordered 9x9 map
+        HIPCK(h, launch_wino_weights(s.wd, s.U, need_pad, L.cout_pad, st));
+        HIPCK(h, launch_embed_9x9(s.dy, s.canvas, G * N, L.cout_pad, st));
+        cw.wu = s.U; cw.pad = 1;
+        c.x = s.canvas; c.H = 9; c.W = 9;
+    }
+    conv_call_common(c, w, wino);
     RC(run_conv(h, cw, c, st));
     const int cfold = round_up(cin_need, 4);
     HIPCK(h, launch_fold_reflect(s.dxp, need_pad, G * N, cfold, add, add_pitch, add_coff, dx, dx_pitch, dx_coff, st));
@@ -305,6 +325,8 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->sc.dxp_floats = imgs * 81 * 1024; t->sc.dxp = a.take(t->sc.dxp_floats);
         t->sc.dy_floats = rows * 512; t->sc.dy = a.take(t->sc.dy_floats);
         t->sc.slab_floats = (size_t)4 * 512 * 9 * 1536; t->sc.slabs = a.take(t->sc.slab_floats);
+        t->sc.U_floats = (size_t)36 * 512 * 1536; t->sc.U = a.take(t->sc.U_floats);
+        t->sc.canvas_floats = imgs * 81 * 512; t->sc.canvas = a.take(t->sc.canvas_floats);
         t->dFeatNew = a.take(rows * 512); t->d512a = a.take(rows * 512); t->d512b = a.take(rows * 512);
         t->dBufM = a.take(rows * 1024); t->extM = a.take(rows * 1024); t->dF = a.take(rows * 1024);
         t->d256a = a.take(rows * 256); t->d256b = a.take(rows * 256); t->d256c = a.take(rows * 256); t->dms = a.take(rows * 64);
@@ -334,7 +356,6 @@ int get_train(ffr_handle* h, TrainState** t) {
 int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream_t st) {
     const int G = c.G, N = c.N, imgs = G * N, rows = imgs * 49;
     const long long crow = (long long)imgs * 512;
-    double* part = t->sc.part;
     HIPCK(h, launch_copy_slice(c.X, c.bufS, rows, 512, 576, 0, st));
     HIPCK(h, launch_copy_slice(c.X, c.bufM, rows, 512, 1536, 1024, st));
     HIPCK(h, launch_selfsim_space(c.X, c.bufS, 576, nullptr, imgs, st));
@@ -342,7 +363,7 @@ int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream
     auto L = [&](const TLayer& Ly, TSaved& sv, const float* x, int x_pitch, const float* resid, int res_pitch, float* out,
                  int out_pitch, int out_coff, int flags) -> int {
         sv.x = x; sv.x_pitch = x_pitch;
-        return layer_forward(h, w, Ly, sv, G, N, resid, res_pitch, out, out_pitch, out_coff, flags, true, part, st);
+        return layer_forward(h, w, Ly, sv, G, N, resid, res_pitch, out, out_pitch, out_coff, flags, true, t->sc, st);
     };
     // Conv4Space (recnet.py:362-371) -> M_space (pitch-64 rows, sigmoid)
     RC(L(t->sp[0], c.sp[0], c.bufS, 576, nullptr, 0, c.out_sp[0], 256, 0, 0));
@@ -539,7 +560,9 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
     s.dxp_floats = (size_t)G * N * 81 * need_pad; RC(dev_alloc_t(h, own, s.dxp_floats, &s.dxp));
     s.dy_floats = (size_t)rows * L.cout_pad; RC(dev_alloc_t(h, own, s.dy_floats, &s.dy));
     s.slab_floats = (size_t)16 * wp.size(); RC(dev_alloc_t(h, own, s.slab_floats, &s.slabs));
-    RC(layer_forward(h, w, L, sv, G, N, nullptr, 0, out_nhwc, L.cout_pad, 0, 0, true, s.part, st));
+    s.U_floats = (size_t)36 * L.cout_pad * (L.cin_pad > need_pad ? L.cin_pad : need_pad); RC(dev_alloc_t(h, own, s.U_floats, &s.U));
+    s.canvas_floats = (size_t)G * N * 81 * L.cout_pad; RC(dev_alloc_t(h, own, s.canvas_floats, &s.canvas));
+    RC(layer_forward(h, w, L, sv, G, N, nullptr, 0, out_nhwc, L.cout_pad, 0, 0, true, s, st));
     RC(layer_backward(h, w, L, sv, G, N, da_nhwc, L.cout_pad, 0, 0, s, dx_nhwc, L.cin_pad, 0, cin, nullptr, 0, 0, st));
     if (dw_packed) HIPCK(h, hipMemcpyAsync(dw_packed, L.gw, wp.size() * 4, hipMemcpyDeviceToDevice, st));
     if (dvec) HIPCK(h, hipMemcpyAsync(dvec, gv, (size_t)5 * L.cout_pad * 4, hipMemcpyDeviceToDevice, st));
@@ -781,6 +804,15 @@ int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_
     HIPCK(h, hipDeviceSynchronize());
     HIPCK(h, hipMemcpy(host_out, src, n * 4, hipMemcpyDeviceToHost));
     return FFR_OK;
+}
+
+
+int ffr_train_option(ffr_handle* h, const char* name, int value) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (!name) return fail(h, FFR_ERR_ARG, "ffr_train_option: null name");
+    if (std::string(name) == "winograd") { t->sc.wino = value != 0; return FFR_OK; }
+    return fail(h, FFR_ERR_KEY, "ffr_train_option: unknown option '%s'", name);
 }
 
 }  // extern "C"

@@ -48,6 +48,8 @@ hipError_t launch_bn_bwd(const float* da, int da_pitch, int da_coff, const float
 // Wd[ci][8 - t][co] = W[co][t][ci]: the rotated / transposed 3x3 weights of the data-gradient convolution.
 // W [cout_pad][9][cin_pad] -> Wd [cinD_pad][9][cout_pad], rows ci >= cin_pad are zero.
 hipError_t launch_pack_dgrad(const float* W, int cout_pad, int cin_pad, float* Wd, int cinD_pad, hipStream_t stream);
+// canvas[imgs][9][9][Cp]: dy[imgs][7][7][Cp] at offset (1,1), zero border
+hipError_t launch_embed_9x9(const float* dy, float* canvas, int imgs, int Cp, hipStream_t stream);
 // adjoint of ReflectionPad2d(1) on 7x7: dx[img][h][w] = sum of the dxp[img][9][9] entries that read (h, w);
 // out[row][out_coff + c] = fold (+ add[row][add_coff + c])     (C channels, multiples of 4 everywhere)
 hipError_t launch_fold_reflect(const float* dxp, int p_pitch, int imgs, int C, const float* add, int add_pitch,

@@ -154,6 +154,42 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
     }
 }
 
+// U[xi][o][i] = (G g G^T)[xi] of the 3x3 filter g = W[o][0..8][i]  (W [out_pad][9][in_pad], tap = r*3+s).
+// Training re-derives U from the master weights every step (the weights move); inference packs it once on the host.
+__global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ W, float* __restrict__ U, int out_pad,
+                                                     int in_pad) {
+    const int iq = in_pad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)out_pad * iq) return;
+    const int o = (int)(idx / iq);
+    const int i4 = (int)(idx - (long long)o * iq) * 4;
+    f32x4 g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = *reinterpret_cast<const f32x4*>(W + ((size_t)o * 9 + t) * in_pad + i4);
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    f32x4 tmp[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tmp[i][c] = G[i][0] * g[c] + G[i][1] * g[3 + c] + G[i][2] * g[6 + c];
+    const size_t plane = (size_t)out_pad * in_pad;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+            *reinterpret_cast<f32x4*>(U + (size_t)(i * 6 + j) * plane + (size_t)o * in_pad + i4) = u;
+        }
+}
+
+hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream) {
+    if (in_pad & 3) return hipErrorInvalidValue;
+    const long long total = (long long)out_pad * (in_pad >> 2);
+    hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, U, out_pad, in_pad);
+    return hipGetLastError();
+}
+
 hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
                           hipStream_t stream) {
     const int th = (H + 3) / 4, tw = (W + 3) / 4;

@@ -80,6 +80,7 @@ SYMBOLS = [
     ('ffr_train_backward', C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     ('ffr_train_adam_step', C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     ('ffr_train_debug_copy', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
+    ('ffr_train_option', C.c_int, [_P, C.c_char_p, C.c_int]),
 ]
 
 
@@ -427,6 +428,9 @@ class Engine(object):
                 _check_dev(g, 'grad')
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_train_backward(self._h, slot, *[_ptr(g) for g in gs], self._stream()))
+
+    def train_option(self, name, value):
+        self._ck(self.lib.ffr_train_option(self._h, name.encode(), int(value)))
 
     def train_debug(self, name, shape, slot=0):
         out = torch.empty(shape, dtype=torch.float32)

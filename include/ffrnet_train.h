@@ -81,6 +81,11 @@ int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const floa
 int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, double eps, double weight_decay,
                         double clip_value, void* stream);
 
+/* Options of the training state. "winograd" (default 1): the 3x3 convolutions of the forward and of the data
+ * gradient with >= 128 input channels run as Winograd F(4x4,3x3) (weights transformed on the device from the
+ * live master weights at every use); 0 = direct implicit GEMM everywhere.                               */
+int ffr_train_option(ffr_handle* h, const char* name, int value);
+
 /* Test hook: the first n floats of a named intermediate buffer of context `slot` (forward activations:
  * "X" "cat" "h1pre" "h1" "t2" "h2pre" "h3pre" "Mc" "raw" "Xht"; backward scratch: "d32a" "d32b" "dMc" "dt"
  * "dBufM" "dF" "dms") copied to host memory, in the kernel layouts.  Synchronises the device.          */
