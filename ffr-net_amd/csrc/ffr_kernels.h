@@ -54,6 +54,9 @@ hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pit
                           hipStream_t stream);
 // U[36][out_pad][in_pad] = G g G^T of W[out_pad][9][in_pad] (device-side; the training step re-derives it per step)
 hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream);
+// weight gradient in the Winograd domain: dM[36][T][Cp] = A dy A^T per 4x4 output tile; grad[o][9][i] (+)= G^T dU G
+hipError_t launch_wino_dout(const float* dy, float* dM, int N, int H, int W, int Cp, hipStream_t stream);
+hipError_t launch_wino_dweights(const float* dU, float* grad, int out_pad, int in_pad, int accumulate, hipStream_t stream);
 // out = epilogue(A^T M A): bias[(border class)][cout_pad], PReLU, residual, sigmoid (flags bit0)
 hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
                            float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,

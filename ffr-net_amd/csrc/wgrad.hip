@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
     int bid = blockIdx.x;
     const int nt = bid % a.ntiles; bid /= a.ntiles;
     const int mt = bid % a.mtiles; bid /= a.mtiles;
-    const int split = bid;
+    const int split = bid % a.splits;
+    const int batch = bid / a.splits;
+    const float* const dyb = a.dy + (long long)batch * a.dy_bstride;
+    const float* const xb = a.x + (long long)batch * a.x_bstride;
     const int co0 = mt * BM, n0 = nt * BN;
     const int kt0 = split * a.kt_per_split;
     int kt1 = kt0 + a.kt_per_split;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
             const int piece = (q * 4 + wave) * 64;              // first piece of this instruction
             const int k = (piece + lane) / (BM / 4);
             const int m = m0 + k;
-            const float* src = (m < a.rows) ? a.dy + (size_t)m * a.dy_pitch + co0 + clA * 4 : a.zero;
+            const float* src = (m < a.rows) ? dyb + (size_t)m * a.dy_pitch + co0 + clA * 4 : a.zero;
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + piece * 4), 16, 0, 0);
         }
 #pragma unroll
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
                 } else {
                     ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
                 }
-                if (ok) src = a.x + ((size_t)img * HW + h * a.W + w) * a.x_pitch + ci;
+                if (ok) src = xb + ((size_t)img * HW + h * a.W + w) * a.x_pitch + ci;
             }
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sB + piece * 4), 16, 0, 0);
         }
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
         }
     }
     // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* out = a.out + (size_t)split * a.cout_pad * a.Ng;
+    float* out = a.out + (size_t)split * a.cout_pad * a.Ng + (long long)batch * a.out_bstride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -189,12 +192,32 @@ hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch
     splits = (a.nkt + a.kt_per_split - 1) / a.kt_per_split;
     a.splits = splits;
     a.out = scratch;
+    a.nbatch = 1; a.dy_bstride = 0; a.x_bstride = 0; a.out_bstride = 0;
     const unsigned grid = (unsigned)(tiles * splits);
     if (bm == 128) hipLaunchKernelGGL(k_wgrad<128>, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(k_wgrad<64>, dim3(grid), dim3(256), 0, stream, a);
     const long long n4 = (long long)per / 4;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, grad, n4, splits,
                        accumulate);
+    return hipGetLastError();
+}
+
+// nbatch independent products out[b][cout_pad][cin_pad] = dy[b]^T x[b] (no split-K, no reduction pass):
+// the 36 Winograd-domain weight gradients dU[xi] = dM[xi]^T V[xi]
+hipError_t launch_wgrad_batched(WgradArgs a, float* out, int nbatch, long long dy_bstride, long long x_bstride,
+                                hipStream_t stream) {
+    if (a.cout_pad % 64 || a.cin_pad % 4 || a.taps != 1 || a.rows <= 0 || nbatch <= 0) return hipErrorInvalidValue;
+    a.Ng = a.cin_pad;
+    const int bm = (a.cout_pad % 128 == 0) ? 128 : 64;
+    a.mtiles = a.cout_pad / bm;
+    a.ntiles = (a.Ng + 127) / 128;
+    a.nkt = (a.rows + 31) / 32;
+    a.splits = 1; a.kt_per_split = a.nkt;
+    a.out = out;
+    a.nbatch = nbatch; a.dy_bstride = dy_bstride; a.x_bstride = x_bstride; a.out_bstride = (long long)a.cout_pad * a.Ng;
+    const unsigned grid = (unsigned)((long long)a.mtiles * a.ntiles * nbatch);
+    if (bm == 128) hipLaunchKernelGGL(k_wgrad<128>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(k_wgrad<64>, dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

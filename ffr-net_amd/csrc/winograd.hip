@@ -190,6 +190,109 @@ hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad
     return hipGetLastError();
 }
 
+// ---- weight gradient in the Winograd domain (training step) ---------------------------------------------
+// Y = A^T M A per tile  =>  dM = A dY A^T;   U = G g G^T  =>  dg = G^T dU G;   dU[xi][co][ci] = sum_tiles dM V
+// m = A y  (A is the transpose of the 4x6 output-transform matrix)
+__device__ __forceinline__ void a6(const f32x4 y[4], f32x4 m[6]) {
+    const f32x4 e = y[0] + y[2], o = y[1] + y[3];
+    const f32x4 e4 = y[0] + 4.f * y[2], o8 = 2.f * y[1] + 8.f * y[3];
+    m[0] = y[0];
+    m[1] = e + o;
+    m[2] = e - o;
+    m[3] = e4 + o8;
+    m[4] = e4 - o8;
+    m[5] = y[3];
+}
+
+// dM[36][T][Cp] from dy[N][H][W][Cp] (gradient wrt the raw convolution output); outputs beyond the map are zero
+__global__ __launch_bounds__(256) void k_wino_dout(const float* __restrict__ dy, float* __restrict__ dM, int H, int W, int Cp,
+                                                  int th, int tw, long long T) {
+    const int cq = Cp >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * cq) return;
+    const long long t = idx / cq;
+    const int c4 = (int)(idx - t * cq) * 4;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const long long n = t / ((long long)tw * th);
+    const float* base = dy + (size_t)n * H * W * Cp + c4;
+    f32x4 tmp[6][4];     // A applied to the columns: [i][col]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 y[4], m[6];
+        const int ow = tx * 4 + j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oh = ty * 4 + i;
+            y[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (oh < H && ow < W) y[i] = *reinterpret_cast<const f32x4*>(base + ((size_t)oh * W + ow) * Cp);
+        }
+        a6(y, m);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = m[i];
+    }
+    float* out = dM + (size_t)t * Cp + c4;
+    const size_t plane = (size_t)T * Cp;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 m[6];
+        a6(tmp[i], m);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(out + (size_t)(i * 6 + j) * plane) = m[j];
+    }
+}
+
+hipError_t launch_wino_dout(const float* dy, float* dM, int N, int H, int W, int Cp, hipStream_t stream) {
+    if (Cp & 3) return hipErrorInvalidValue;
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)N * th * tw;
+    const long long total = T * (Cp >> 2);
+    hipLaunchKernelGGL(k_wino_dout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, dM, H, W, Cp, th, tw, T);
+    return hipGetLastError();
+}
+
+// grad[o][t][i] (+)= (G^T dU G)[t] for dU[36][out_pad][in_pad]
+__global__ __launch_bounds__(256) void k_wino_dweights(const float* __restrict__ dU, float* __restrict__ grad, int out_pad,
+                                                      int in_pad, int accumulate) {
+    const int iq = in_pad >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)out_pad * iq) return;
+    const int o = (int)(idx / iq);
+    const int i4 = (int)(idx - (long long)o * iq) * 4;
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    const size_t plane = (size_t)out_pad * in_pad;
+    const float* src = dU + (size_t)o * in_pad + i4;
+    f32x4 tmp[3][6];     // G^T applied to the rows: [r][j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 u[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) u[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(i * 6 + j) * plane);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            tmp[r][j] = G[0][r] * u[0] + G[1][r] * u[1] + G[2][r] * u[2] + G[3][r] * u[3] + G[4][r] * u[4] + G[5][r] * u[5];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 g = G[0][c] * tmp[r][0] + G[1][c] * tmp[r][1] + G[2][c] * tmp[r][2] + G[3][c] * tmp[r][3] +
+                      G[4][c] * tmp[r][4] + G[5][c] * tmp[r][5];
+            float* dst = grad + ((size_t)o * 9 + r * 3 + c) * in_pad + i4;
+            if (accumulate) g += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = g;
+        }
+}
+
+hipError_t launch_wino_dweights(const float* dU, float* grad, int out_pad, int in_pad, int accumulate, hipStream_t stream) {
+    if (in_pad & 3) return hipErrorInvalidValue;
+    const long long total = (long long)out_pad * (in_pad >> 2);
+    hipLaunchKernelGGL(k_wino_dweights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dU, grad, out_pad, in_pad,
+                       accumulate);
+    return hipGetLastError();
+}
+
 hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
                           hipStream_t stream) {
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
