@@ -829,4 +829,36 @@ int ffr_train_option(ffr_handle* h, const char* name, int value) {
     return fail(h, FFR_ERR_KEY, "ffr_train_option: unknown option '%s'", name);
 }
 
+
+// device-to-device conversion of one entry: dir 0 = export (kernel layout -> torch layout), 1 = import
+static int train_convert(ffr_handle* h, int which, const char* key, float* dev, int dir, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (!key || !dev) return fail(h, FFR_ERR_ARG, "ffr_train_export/import: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (which == 4) {
+        auto it = t->running_of.find(key);
+        if (it == t->running_of.end()) return fail(h, FFR_ERR_KEY, "no running statistic '%s'", key);
+        if (dir) HIPCK(h, hipMemcpyAsync(it->second.first, dev, (size_t)it->second.second * 4, hipMemcpyDeviceToDevice, st));
+        else HIPCK(h, hipMemcpyAsync(dev, it->second.first, (size_t)it->second.second * 4, hipMemcpyDeviceToDevice, st));
+        return FFR_OK;
+    }
+    auto it = t->seg_of.find(key);
+    if (it == t->seg_of.end()) return fail(h, FFR_ERR_KEY, "no parameter '%s'", key);
+    const Seg& sg = t->segs[it->second];
+    float* base = which == 0 ? t->P : which == 1 ? t->Gr : which == 2 ? t->M1 : which == 3 ? t->M2 : nullptr;
+    if (!base) return fail(h, FFR_ERR_ARG, "which must be 0..4");
+    HIPCK(h, launch_seg_convert(base + sg.off, dev, sg.n_natural, sg.kind == SEG_CONV ? 0 : sg.kind == SEG_VEC ? 1 : 2, sg.d1,
+                                sg.p1, sg.colperm, dir, st));
+    return FFR_OK;
+}
+
+int ffr_train_export(ffr_handle* h, int which, const char* key, float* dev_out, void* stream) {
+    return train_convert(h, which, key, dev_out, 0, stream);
+}
+
+int ffr_train_import(ffr_handle* h, int which, const char* key, const float* dev_in, void* stream) {
+    return train_convert(h, which, key, const_cast<float*>(dev_in), 1, stream);
+}
+
 }  // extern "C"

@@ -114,6 +114,10 @@ hipError_t launch_cosface_dcos(const float* d_pred_loss, const float* d_pred_lab
 hipError_t launch_normalize_bwd(const float* dv, int dv_pitch, const float* v, const float* norm, const float* ext,
                                 float* du, int du_pitch, int accumulate, int rows, hipStream_t stream);
 
+// one state_dict entry between the torch layout (`natural`) and the kernel layout (`native`), both on the device
+hipError_t launch_seg_convert(float* native, float* natural, size_t n, int kind, int d1, int p1, int colperm, int to_native,
+                              hipStream_t stream);
+
 // ---- optimiser (models/trainer.py:115-121,182-187) -----------------------------------------------------
 // clip_grad_value_(clip) then torch.optim.Adam: p, g, m, v flat arrays of n floats; step counts from 1
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,

@@ -798,4 +798,32 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, size_t n, d
     return hipGetLastError();
 }
 
+// ---- torch layout <-> kernel layout of one state_dict entry, on the device ---------------------------------
+// kind 0: conv [d0][d1][3][3] <-> [p0][9][p1]; 1: vector; 2: linear [d0][d1] <-> [p0][p1] (colperm: the
+// Linear(561,32) columns are stored as [ss_channel (512) | X (49) | pad])
+__global__ __launch_bounds__(256) void k_seg_convert(float* __restrict__ native, float* __restrict__ natural, size_t n,
+                                                    int kind, int d1, int p1, int colperm, int to_native) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    size_t j = i;
+    if (kind == 0) {
+        const size_t t = i % 9, ci = (i / 9) % d1, co = i / 9 / d1;
+        j = (co * 9 + t) * p1 + ci;
+    } else if (kind == 2) {
+        const size_t in = i % d1, o = i / d1;
+        const size_t col = colperm ? (in < 49 ? 512 + in : in - 49) : in;
+        j = o * p1 + col;
+    }
+    if (to_native) native[j] = natural[i];
+    else natural[i] = native[j];
+}
+
+hipError_t launch_seg_convert(float* native, float* natural, size_t n, int kind, int d1, int p1, int colperm, int to_native,
+                              hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_convert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, native, natural, n, kind, d1, p1,
+                       colperm, to_native);
+    return hipGetLastError();
+}
+
 }  // namespace ffr

@@ -203,9 +203,83 @@ class RecNet(_NativeModule):
         self.classifier = AddMarginProduct(channel)
 
     def forward(self, input, label=None):
-        """label=None -> (f_new[N,512], feat_new[N,512,7,7]); models/recnet.py:398-426."""
+        """label=None (eval) -> (f_new[N,512], feat_new[N,512,7,7]), models/recnet.py:398-426.
+        label given (train) -> the 7-tuple of models/recnet.py:427-429, differentiable with respect to the
+        module's parameters through the native backward (include/ffrnet_train.h)."""
         if label is not None:
-            raise NotImplementedError('ffrnet_amd.RecNet: the label branch (recnet.py:427-429) is '
-                                      'the training path and is not implemented natively')
+            return self._forward_train(input, label)
         self._require_native(input, 'RecNet')
         return self._engine(input.device).recnet_forward(input)
+
+    # -- training branch: RecNet.forward(input, label) in train() mode ------------------------------------
+    def _train_engine(self, device):
+        """Engine whose training state mirrors this module's parameters: built from state_dict() once per device,
+        afterwards only tensors whose version moved (an optimiser step, load_state_dict) are re-imported, on
+        the device."""
+        cache = self.__dict__.setdefault('_native_cache', {})
+        ent = cache.get(('train', device.index))
+        sd = self.state_dict(keep_vars=True)
+        if ent is None:
+            eng = Engine(device.index)
+            eng.train_init({k: v.detach() for k, v in sd.items()})
+            ent = [eng, {k: (id(v), v._version) for k, v in sd.items()}, 0]
+            cache[('train', device.index)] = ent
+            return ent
+        eng, seen, _ = ent
+        for k, v in sd.items():
+            sig = (id(v), v._version)
+            if seen.get(k) == sig or k.endswith('num_batches_tracked'):
+                continue
+            if k.endswith(('running_mean', 'running_var')):
+                eng.train_import(k, v.detach().to(device), 'running')
+            else:
+                eng.train_import(k, v.detach().to(device), 'param')
+            seen[k] = sig
+        return ent
+
+    def _forward_train(self, input, label):
+        if not self.training:
+            raise NotImplementedError('ffrnet_amd.RecNet: forward(input, label) is the train() branch '
+                                      '(models/recnet.py:427-429); call .train() first')
+        if not (torch.is_tensor(input) and input.is_cuda and input.dtype == torch.float32):
+            raise RuntimeError('ffrnet_amd.RecNet: input must be a float32 ROCm device tensor; this package has no CPU path')
+        ent = self._train_engine(input.device)
+        eng = ent[0]
+        slot = ent[2] % 2
+        ent[2] += 1
+        names = [k for k, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        outs = _RecNetTrainFn.apply(eng, slot, names, input, label, *params)
+        # BatchNorm buffers follow the native running statistics (models/recnet.py:141-143 in train mode)
+        with torch.no_grad():
+            seen = ent[1]
+            for k, b in self.named_buffers():
+                if k.endswith(('running_mean', 'running_var')):
+                    eng.train_export(k, b.data, 'running')
+                elif k.endswith('num_batches_tracked'):
+                    b += 1
+                seen[k] = (id(b), b._version)
+        return outs
+
+
+class _RecNetTrainFn(torch.autograd.Function):
+    """RecNet.forward(input, label) in train() mode with the native backward behind torch.autograd: parameter
+    gradients come back in torch layout; the input gets none (the encoder is frozen, models/trainer.py:62-63)."""
+
+    @staticmethod
+    def forward(ctx, eng, slot, names, input, label, *params):
+        ctx.eng, ctx.slot, ctx.names = eng, slot, names
+        ctx.shapes = [tuple(p.shape) for p in params]
+        outs = eng.train_forward(input.detach(), label, groups=1, slot=slot)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        eng = ctx.eng
+        eng.train_zero_grad()
+        eng.train_backward([g if g is not None else None for g in gouts], slot=ctx.slot)
+        grads = []
+        dev = eng.device
+        for k, shp in zip(ctx.names, ctx.shapes):
+            grads.append(eng.train_export(k, torch.empty(shp, device=dev, dtype=torch.float32), 'grad'))
+        return (None, None, None, None, None) + tuple(grads)

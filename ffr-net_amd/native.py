@@ -81,6 +81,8 @@ SYMBOLS = [
     ('ffr_train_adam_step', C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     ('ffr_train_debug_copy', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
     ('ffr_train_option', C.c_int, [_P, C.c_char_p, C.c_int]),
+    ('ffr_train_export', C.c_int, [_P, C.c_int, C.c_char_p, _P, _P]),
+    ('ffr_train_import', C.c_int, [_P, C.c_int, C.c_char_p, _P, _P]),
 ]
 
 
@@ -428,6 +430,22 @@ class Engine(object):
                 _check_dev(g, 'grad')
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_train_backward(self._h, slot, *[_ptr(g) for g in gs], self._stream()))
+
+    _WHICH = {'param': 0, 'grad': 1, 'exp_avg': 2, 'exp_avg_sq': 3, 'running': 4}
+
+    def train_export(self, key, out, which='grad'):
+        """One entry in torch layout into the device tensor `out` (no host round trip)."""
+        _check_dev(out, 'out')
+        assert out.is_contiguous() and out.dtype == torch.float32
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_export(self._h, self._WHICH[which], key.encode(), _ptr(out), self._stream()))
+        return out
+
+    def train_import(self, key, value, which='param'):
+        _check_dev(value, 'value')
+        v = value.detach().contiguous().float()
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_import(self._h, self._WHICH[which], key.encode(), _ptr(v), self._stream()))
 
     def train_option(self, name, value):
         self._ck(self.lib.ffr_train_option(self._h, name.encode(), int(value)))

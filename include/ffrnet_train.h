@@ -55,6 +55,12 @@ int ffr_train_info(ffr_handle* h, float** params, float** grads, size_t* n_flat,
 int ffr_train_get(ffr_handle* h, int which, const char* key, float* host_out, size_t n);
 int ffr_train_set(ffr_handle* h, int which, const char* key, const float* host_in, size_t n);
 
+/* the same per-tensor conversion between DEVICE buffers, asynchronous on `stream` (no host round trip): what
+ * the nn.Module shell ffrnet_amd.RecNet uses to hand parameter gradients to torch autograd and to pick up
+ * parameters a torch optimiser has moved.  dev_out / dev_in: the entry in torch layout, contiguous fp32. */
+int ffr_train_export(ffr_handle* h, int which, const char* key, float* dev_out, void* stream);
+int ffr_train_import(ffr_handle* h, int which, const char* key, const float* dev_in, void* stream);
+
 /* optimizer.zero_grad() (models/trainer.py:184) */
 int ffr_train_zero_grad(ffr_handle* h, void* stream);
 

@@ -299,3 +299,55 @@ def test_train_backward_kink_free_network_both_modes(engine, specs):
             # (the next BatchNorm removes the shift): errors are taken relative to at least 1e-3
             e = ((got.double() - ref.double()).abs().max() / max(ref.abs().max().item(), 1e-3)).item()
             assert e < (1e-4 if mode == 0 else 3e-4), (mode, k, e)
+
+
+def test_recnet_shell_train_branch_two_iterations(specs):
+    """ffrnet_amd.RecNet in train() mode as the reference's Trainer drives it (models/trainer.py:139-187):
+    recnet(featmap, label) twice, the four losses, loss.backward(), clip_grad_value_, torch.optim.Adam.step();
+    then a second iteration, which must see the moved parameters.  Held to the oracle's train_step."""
+    import ffr_oracle as O
+    import ffr_oracle_train as OT
+    from ffrnet_amd import train as T
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    for k in sd_r:                      # smooth network (PReLU slope 1): no kink noise, tight tolerances
+        if k.endswith('func.weight'):
+            sd_r[k] = torch.ones_like(sd_r[k])
+    non, ocl, label = synth.synth_train_batch(4, seed=301)
+    with torch.no_grad():
+        fm_non, fe_non = O.encoder_forward(sd_e, non)
+        fm_ocl, fe_ocl = O.encoder_forward(sd_e, ocl)
+    rec = ffrnet_amd.RecNet(norm_type='bn', relu_type='prelu')
+    rec.load_state_dict(sd_r)
+    rec.cuda().train()
+    # plain SGD between the two iterations: Adam's g / (|g| + eps) turns the rounding noise of mathematically zero
+    # gradients into full-size steps, which would make iteration 2 incomparable (Adam itself: test_adam_and_clip_*)
+    opt = torch.optim.SGD([p for p in rec.parameters() if p.requires_grad], 0.05)
+    sd_o = {k: v.clone() for k, v in sd_r.items()}
+    ost = OT.new_adam_state(sd_o)
+    dev = torch.device('cuda', 0)
+    for it in range(2):
+        # oracle iteration on the same feature maps (encoder_forward is deterministic: recomputed inside)
+        ref = OT.train_step(sd_e, sd_o, ost, non, ocl, label, apply_update=False)
+        for k, g in ref['grads'].items():
+            sd_o[k] -= 0.05 * g
+        out_non = rec(fm_non.to(dev), label.to(dev))
+        out_ocl = rec(fm_ocl.to(dev), label.to(dev))
+        assert len(out_non) == 7 and out_non[1].shape == (4, 10575)
+        items = T.trainer_losses(out_non[0], out_ocl[0], out_non[1], out_ocl[1], out_non[5], out_ocl[5], out_non[6],
+                                 out_ocl[6], fm_non.to(dev), fe_non.to(dev), fe_ocl.to(dev), label.to(dev))
+        assert np.allclose([float(l) for l in items], ref['losses'], rtol=2e-4), (it, [float(l) for l in items], ref['losses'])
+        opt.zero_grad()
+        sum(items).backward()
+        torch.nn.utils.clip_grad_value_(rec.parameters(), 1.0)
+        for k, p in rec.named_parameters():
+            r = ref['grads'][k]
+            e = ((p.grad.cpu().double() - r.double()).abs().max() / max(r.abs().max().item(), 1e-3)).item()
+            assert e < 5e-4, (it, k, e)
+        opt.step()
+    sd_m = rec.state_dict()
+    for k, v in sd_o.items():
+        if k.endswith('num_batches_tracked'):
+            assert int(sd_m[k]) == 4
+        elif k.endswith(('running_mean', 'running_var')):
+            assert rel(sd_m[k], v) < 1e-4, k

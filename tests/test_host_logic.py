@@ -54,7 +54,9 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         rec(torch.zeros(1, 512, 7, 7))
     with pytest.raises(NotImplementedError):
-        rec(torch.zeros(1, 512, 7, 7), label=torch.zeros(1))
+        rec(torch.zeros(1, 512, 7, 7), label=torch.zeros(1))          # label branch needs train()
+    with pytest.raises(RuntimeError):
+        rec.train()(torch.zeros(2, 512, 7, 7), label=torch.zeros(2))   # train branch: device tensors only
     src = ''
     for fn in os.listdir(os.path.join(ROOT, 'ffr-net_amd')):
         if fn.endswith('.py'):
