@@ -29,7 +29,8 @@ template <bool U8>
 __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const unsigned char* __restrict__ xu8,
                                              const unsigned char* __restrict__ flip, const float* __restrict__ w,
                                              const float* __restrict__ bias, const float* __restrict__ slope,
-                                             float* __restrict__ out, int N, int H, int W) {
+                                             float* __restrict__ out, int N, int H, int W,
+                                             const float* __restrict__ x2, int n_split) {
     __shared__ __attribute__((aligned(16))) float patch[STEM_PIX * 28];
     const int tid = threadIdx.x;
     const int cg = tid & 15, pg = tid >> 4;
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
                         const float u = (float)xu8[(((long long)n * H + hi) * W + ws) * 3 + (2 - f_ci[i])];
                         v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.5f), 0.5f);
                     } else {
-                        v = x[((long long)(n * 3 + f_ci[i]) * H + hi) * W + wi];
+                        // images [n_split, N) come from a second buffer (clean | occluded halves of a training batch)
+                        const float* xs = n >= n_split ? x2 : x;
+                        const int nn = n >= n_split ? n - n_split : n;
+                        v = xs[((long long)(nn * 3 + f_ci[i]) * H + hi) * W + wi];
                     }
                 }
                 patch[pix * 28 + (tid & 3) * 7 + i] = v;
@@ -103,12 +107,13 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
 }
 
 hipError_t launch_stem(const float* x, const unsigned char* xu8, const unsigned char* flip, const float* w,
-                       const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream) {
+                       const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream, const float* x2, int n_split) {
     const long long total = (long long)N * H * W;
     const long long per_block = (long long)STEM_PIX * STEM_STEPS;
     const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
-    if (xu8) hipLaunchKernelGGL(k_stem<true>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W);
-    else hipLaunchKernelGGL(k_stem<false>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W);
+    if (!x2) n_split = N;
+    if (xu8) hipLaunchKernelGGL(k_stem<true>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W, x2, n_split);
+    else hipLaunchKernelGGL(k_stem<false>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W, x2, n_split);
     return hipGetLastError();
 }
 

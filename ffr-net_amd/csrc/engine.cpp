@@ -437,11 +437,11 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
 // Runs stem + n_blocks bottlenecks; *out_ptr = NHWC result, *oh/*ow/*oc its geometry.
 
 int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, int W, int n_blocks, hipStream_t st,
-              float** out_ptr, int* oh, int* ow, int* oc, const U8In* u8 = nullptr) {
+              float** out_ptr, int* oh, int* ow, int* oc, const U8In* u8 = nullptr, const float* x2 = nullptr, int n_split = 0) {
     {
         Scope s(h, st, FFR_KC_STEM, 2.0 * N * H * W * 64 * 27, 4.0 * N * H * W * (3 + 64));
         HIPCK(h, launch_stem(x_nchw, u8 ? u8->img : nullptr, u8 ? u8->flip : nullptr, h->stem_w, h->stem_b, h->stem_s,
-                             w.bufA, N, H, W, st));
+                             w.bufA, N, H, W, st, x2, n_split));
     }
     float* cur = w.bufA;
     float* nxt = w.bufB;
@@ -487,9 +487,9 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
 
 // trunk -> featmap (NHWC in w.X / w.trunk_bn) and f
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
-                hipStream_t st, const U8In* u8) {
+                hipStream_t st, const U8In* u8, const float* x2, int n_split) {
     float* t; int oh, ow, oc;
-    RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc, u8));
+    RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc, u8, x2, n_split));
     const int P = oh * ow;
     if (featmap_nhwc) {
         Scope s(h, st, FFR_KC_HEAD, 2.0 * N * P * 512, 8.0 * N * P * 512);

@@ -67,7 +67,8 @@ hipError_t launch_wino_out(const float* M, const float* bias, const float* slope
 // input: x_nchw fp32, OR (xu8 != null) uint8 [N,H,W,3] RGB images preprocessed on the fly
 // (BGR swap, per-image h-flip flags, /255, (x-0.5)/0.5)
 hipError_t launch_stem(const float* x_nchw, const unsigned char* xu8, const unsigned char* flip, const float* w27x64,
-                       const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream);
+                       const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream,
+                       const float* x2 = nullptr, int n_split = 0);   // images [n_split, N) read from x2 (fp32 path)
 // SE: scale[n][c] = sigmoid(fc2(relu(fc1(mean_hw res[n]))))   fc1 [C/16][C], fc2 [C][C/16]
 // part: scratch [N][se_slices(N,HW)][C] floats (<= N*32*512)
 int se_slices(int N, int HW);

@@ -255,6 +255,11 @@ struct TrainState {
     TScratch sc;
     float *dFeatNew, *d512a, *d512b, *dBufM, *extM, *dF, *d256a, *d256b, *d256c, *dms;
     float *dRawt, *dMc, *dt, *d32a, *d32b, *rowdot, *dcos, *dfn, *df, *dwn, *wnT, *wT;
+    // native loss items (ffr_train_losses)
+    float *lYht, *lYh, *df_ext, *loss_out;
+    double *p_sss, *p_ssc, *p_vec, *p_ce;
+    int* hit;
+    bool loss_grads_ready = false;
 };
 
 namespace {
@@ -348,6 +353,9 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->d32a = a.take(crow * 64); t->d32b = a.take(crow * 64); t->rowdot = a.take(crow);
         t->dcos = a.take(imgs * CLS_PAD); t->dfn = a.take(imgs * 512); t->df = a.take(imgs * 512);
         t->dwn = a.take((size_t)CLS_PAD * 512); t->wnT = a.take((size_t)512 * CLS_PAD); t->wT = a.take((size_t)512 * 576);
+        t->lYht = a.take(crow * 64); t->lYh = a.take(imgs * 64 * 512); t->df_ext = a.take(imgs * 512); t->loss_out = a.take(64);
+        t->p_sss = (double*)a.take(imgs * 2 + 64); t->p_ssc = (double*)a.take(imgs * 64 * 2 + 64);
+        t->p_vec = (double*)a.take(imgs * 4 + 64); t->p_ce = (double*)a.take(imgs * 2 + 64); t->hit = (int*)a.take(imgs + 64);
         return a.off;
     };
     const size_t need = carve(nullptr);
@@ -444,7 +452,8 @@ int lin_backward(ffr_handle* h, TrainState* t, const Work& w, const Lin& ln, con
     return FFR_OK;
 }
 
-int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const OutGrads& og, hipStream_t st) {
+// internal: the gradients wrt the outputs were left in the scratch by train_losses (dcos, df_ext, extM)
+int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const OutGrads& og, hipStream_t st, bool internal = false) {
     const int G = c.G, N = c.N, imgs = G * N, rows = imgs * 49;
     const long long crow = (long long)imgs * 512;
     TScratch& s = t->sc;
@@ -453,9 +462,10 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
         return layer_backward(h, w, Ly, sv, G, N, da, da_pitch, da_coff, 1, s, dx, dx_pitch, 0, width, add, add_pitch, add_coff, st);
     };
     // ---- CosFace head and f_new ----------------------------------------------------------------
-    const float* df = og.f_new;
-    if (og.pred_loss || og.pred_label) {
-        HIPCK(h, launch_cosface_dcos(og.pred_loss, og.pred_label, t->dcos, CLS_PAD, imgs, N_CLASSES, COSFACE_S, st));
+    const float* df = internal ? t->df_ext : og.f_new;
+    const float* df_in = df;
+    if (internal || og.pred_loss || og.pred_label) {
+        if (!internal) HIPCK(h, launch_cosface_dcos(og.pred_loss, og.pred_label, t->dcos, CLS_PAD, imgs, N_CLASSES, COSFACE_S, st));
         HIPCK(h, launch_transpose_pad(c.wn, CLS_PAD, 512, 512, t->wnT, 512, CLS_PAD, st));
         RC(gemm_rows(h, w, t->dcos, CLS_PAD, CLS_PAD, t->wnT, nullptr, 512, t->dfn, 512, imgs, nullptr, 0, 0, st));
         WgradArgs a{};
@@ -463,15 +473,17 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
         a.cin_pad = 512; a.taps = 1; a.pad_mode = 0; a.cout_pad = CLS_PAD;
         HIPCK(h, launch_wgrad(a, t->dwn, 0, s.slabs, s.slab_floats, st));
         HIPCK(h, launch_normalize_bwd(t->dwn, 512, c.wn, c.wnorm, nullptr, t->gclsW, 512, 1, N_CLASSES, st));
-        HIPCK(h, launch_normalize_bwd(t->dfn, 512, c.fn, c.fnorm, og.f_new, t->df, 512, 0, imgs, st));
+        HIPCK(h, launch_normalize_bwd(t->dfn, 512, c.fn, c.fnorm, df_in, t->df, 512, 0, imgs, st));
         df = t->df;
     }
     if (df) HIPCK(h, launch_avgpool_bwd(df, nullptr, t->dFeatNew, imgs, 512, st));
     else HIPCK(h, hipMemsetAsync(t->dFeatNew, 0, (size_t)rows * 512 * 4, st));
     // external gradients wrt feat_space / feat_channel (NCHW) -> extM [rows][1024]
-    if (og.feat_space) HIPCK(h, launch_nchw_to_nhwc(og.feat_space, t->extM, 1024, imgs, 49, 512, st));
+    if (internal) { /* extM was filled by train_losses */ }
+    else if (og.feat_space) HIPCK(h, launch_nchw_to_nhwc(og.feat_space, t->extM, 1024, imgs, 49, 512, st));
     else HIPCK(h, launch_fill(t->extM, 0.f, (size_t)rows * 1024, st));
-    if (og.feat_channel) HIPCK(h, launch_nchw_to_nhwc(og.feat_channel, t->extM + 512, 1024, imgs, 49, 512, st));
+    if (internal) { }
+    else if (og.feat_channel) HIPCK(h, launch_nchw_to_nhwc(og.feat_channel, t->extM + 512, 1024, imgs, 49, 512, st));
     else if (og.feat_space) {
         // zero the second half only
         HIPCK(h, hipMemset2DAsync(t->extM + 512, 1024 * 4, 0, 512 * 4, rows, st));
@@ -513,6 +525,36 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     RC(LB(t->sp[2], c.sp[2], t->d256c, 256, 0, t->d256a, 256, 256, nullptr, 0, 0));
     RC(LB(t->sp[1], c.sp[1], t->d256a, 256, 0, t->d256b, 256, 256, t->d256c, 256, 0));
     RC(LB(t->sp[0], c.sp[0], t->d256b, 256, 0, nullptr, 0, 0, nullptr, 0, 0));
+    return FFR_OK;
+}
+
+// ---- the four loss items (models/trainer.py:154-178) and their gradients wrt the outputs of `c` (G == 2) ----------
+int train_losses(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const float* f_enc, const double lw[4], hipStream_t st) {
+    if (c.G != 2) return fail(h, FFR_ERR_ARG, "the loss items need the clean and the occluded half in one forward (G = 2)");
+    const int N = c.N, imgs = 2 * N;
+    LossCoef k;
+    k.w_ss_space = (float)(lw[0] / (4.0 * N * 49.0 * 49.0));
+    k.w_ss_channel = (float)(lw[0] / (4.0 * N * 512.0 * 512.0));
+    k.w_triplet = (float)(lw[1] / N);
+    k.w_identity = (float)(lw[2] / (2.0 * N * 512.0));
+    k.w_ce_non = (float)(lw[3] / ((1e-8 + lw[3]) * N));
+    k.w_ce_ocl = (float)(lw[3] / N);
+    // ss_channel term on feat_channel (bufM[:, 512:1024]): Gram, difference to the target (ss_channel of the clean
+    // feature map = the first 512 columns of channelF_cat), gradient back through the Gram and the normalisation
+    HIPCK(h, launch_loss_ch_prep(c.bufM, 1536, 512, t->lYht, t->lYh, t->rowdot, imgs, st));
+    RC(gemm_batched(h, w, t->lYht, 512 * 64, 64, t->lYht, 512 * 64, 512, t->dMc, 512, (long long)512 * 512, 512, imgs, st));
+    int n_ssc = 0;
+    HIPCK(h, launch_ssc_loss_grad(t->dMc, c.cat, imgs, N, k.w_ss_channel, t->p_ssc, &n_ssc, st));
+    RC(gemm_batched(h, w, t->dMc, (long long)512 * 512, 512, t->lYh, 64 * 512, 64, t->dRawt, 64, 512 * 64, 512, imgs, st));
+    HIPCK(h, launch_loss_ch_finish(t->dRawt, t->lYht, t->rowdot, t->extM, 1024, 512, imgs, st));
+    // ss_space term on feat_space (bufM[:, 0:512])
+    HIPCK(h, launch_ss_space_loss(c.bufM, 1536, 0, c.bufS, imgs, N, k.w_ss_space, t->p_sss, t->extM, 1024, 0, st));
+    HIPCK(h, launch_vec_losses(c.fnew, f_enc, N, 2.0f * k.w_identity, k.w_triplet, 0.1f, t->df_ext, t->p_vec, st));
+    HIPCK(h, launch_ce_loss(c.cosv, CLS_PAD, c.label, N, N_CLASSES, COSFACE_S, COSFACE_M, k.w_ce_non, k.w_ce_ocl, t->dcos,
+                            t->p_ce, t->hit, st));
+    LossParts lp{t->p_sss, t->p_ssc, t->p_vec, t->p_ce, t->hit, n_ssc};
+    HIPCK(h, launch_loss_finish(lp, N, k, t->loss_out, st));
+    t->loss_grads_ready = true;
     return FFR_OK;
 }
 
@@ -813,7 +855,8 @@ int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_
     const float* src = k == "cat" ? c.cat : k == "h1pre" ? c.h1pre : k == "h1" ? c.h1 : k == "t2" ? c.t2 : k == "h2pre" ? c.h2pre :
                        k == "h3pre" ? c.h3pre : k == "Mc" ? c.Mc : k == "raw" ? c.raw : k == "X" ? c.X : k == "Xht" ? c.Xht :
                        k == "d32a" ? t->d32a : k == "d32b" ? t->d32b : k == "dMc" ? t->dMc : k == "dt" ? t->dt :
-                       k == "dBufM" ? t->dBufM : k == "dF" ? t->dF : k == "dms" ? t->dms : nullptr;
+                       k == "dBufM" ? t->dBufM : k == "dF" ? t->dF : k == "dms" ? t->dms : k == "df_ext" ? t->df_ext :
+                       k == "dcos" ? t->dcos : k == "extM" ? t->extM : nullptr;
     if (!src) return fail(h, FFR_ERR_KEY, "no intermediate named '%s'", name);
     HIPCK(h, hipDeviceSynchronize());
     HIPCK(h, hipMemcpy(host_out, src, n * 4, hipMemcpyDeviceToHost));
@@ -859,6 +902,71 @@ int ffr_train_export(ffr_handle* h, int which, const char* key, float* dev_out, 
 
 int ffr_train_import(ffr_handle* h, int which, const char* key, const float* dev_in, void* stream) {
     return train_convert(h, which, key, const_cast<float*>(dev_in), 1, stream);
+}
+
+
+int ffr_train_losses(ffr_handle* h, int slot, const float* f_enc, const double* loss_weight, float* out5, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (slot < 0 || slot > 1 || !f_enc || !loss_weight) return fail(h, FFR_ERR_ARG, "ffr_train_losses: bad arguments");
+    Ctx& c = t->ctx[slot];
+    if (!c.valid) return fail(h, FFR_ERR_STATE, "ffr_train_losses: no forward recorded in slot %d", slot);
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, c.G * c.N, 112, 112, &w));
+    RC(ensure_scratch(h, t, c.G * c.N));
+    RC(train_losses(h, t, c, w, f_enc, loss_weight, st));
+    if (out5) HIPCK(h, hipMemcpyAsync(out5, t->loss_out, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FFR_OK;
+}
+
+int ffr_train_backward_losses(ffr_handle* h, int slot, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    if (slot < 0 || slot > 1) return fail(h, FFR_ERR_ARG, "ffr_train_backward_losses: bad slot");
+    Ctx& c = t->ctx[slot];
+    if (!c.valid || !t->loss_grads_ready) return fail(h, FFR_ERR_STATE, "ffr_train_backward_losses: call ffr_train_forward and ffr_train_losses first");
+    hipStream_t st = (hipStream_t)stream;
+    Work w;
+    RC(ensure_arena(h, c.G * c.N, 112, 112, &w));
+    OutGrads og{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RC(train_backward(h, t, c, w, og, st, true));
+    c.valid = false;
+    t->loss_grads_ready = false;
+    return FFR_OK;
+}
+
+// One iteration up to the gradients (train.py:46-54 without the optimiser step): encoder on both halves (frozen, eval),
+// RecNet train-mode forward, the four loss items, zero_grad, backward.  The caller averages the flat gradient buffer
+// over the ranks (if any) and calls ffr_train_adam_step.
+int ffr_train_iteration(ffr_handle* h, const float* img_non, const float* img_ocl, const int32_t* label, int N,
+                        const double* loss_weight, float* out5, void* stream) {
+    TrainState* t;
+    RC(get_train(h, &t));
+    RC(check_fwd(h, true, false, N));
+    if (!img_non || !img_ocl || !label || !loss_weight) return fail(h, FFR_ERR_ARG, "ffr_train_iteration: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int imgs = 2 * N;
+    Work w;
+    RC(ensure_arena(h, imgs, 112, 112, &w));
+    RC(ensure_scratch(h, t, imgs));
+    Ctx& c = t->ctx[0];
+    RC(ensure_ctx(h, t, c, 2, N));
+    // the encoder writes the NHWC feature maps straight into the context (no NCHW round trip); f -> dfn/df scratch rows
+    float* f_enc = t->d512a;    // [2N][512]; this scratch is free until the backward starts
+    // both halves in one pass of 2N images: the stem reads the second half from img_ocl
+    RC(run_encoder(h, w, img_non, imgs, 112, 112, c.X, f_enc, st, nullptr, img_ocl, N));
+    HIPCK(h, hipMemcpyAsync(c.label, label, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemcpyAsync(c.label + N, label, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    RC(train_forward(h, t, c, w, st));
+    RC(train_losses(h, t, c, w, f_enc, loss_weight, st));
+    if (out5) HIPCK(h, hipMemcpyAsync(out5, t->loss_out, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, st));
+    OutGrads og{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    RC(train_backward(h, t, c, w, og, st, true));
+    c.valid = false;
+    t->loss_grads_ready = false;
+    return FFR_OK;
 }
 
 }  // extern "C"

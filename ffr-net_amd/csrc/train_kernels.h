@@ -114,6 +114,36 @@ hipError_t launch_cosface_dcos(const float* d_pred_loss, const float* d_pred_lab
 hipError_t launch_normalize_bwd(const float* dv, int dv_pitch, const float* v, const float* norm, const float* ext,
                                 float* du, int du_pitch, int accumulate, int rows, hipStream_t stream);
 
+// ---- the four loss items of Trainer.backward (models/trainer.py:154-178), forward value and gradient ----------
+// All kernels write per-block / per-row partial values (doubles) that launch_loss_finish adds in a fixed order.
+struct LossCoef { float w_ss_space, w_ss_channel, w_triplet, w_identity, w_ce_non, w_ce_ocl; };   // incl. loss_weight and 1/count
+// feat_channel slice (NHWC, pitch/coff) -> Yht[imgs][512][64] (channel vectors / max(norm,1e-12), zero padded),
+// Yh_nhwc[imgs][64][512] (the same, position-major, rows >= 49 zero), ynorm[imgs*512]
+hipError_t launch_loss_ch_prep(const float* feat, int pitch, int coff, float* Yht, float* Yh_nhwc, float* ynorm, int imgs,
+                               hipStream_t stream);
+// S[n][512][512] (Gram of Yht) vs the target S0 = cat[(n % N)*512 + c][0..511] (pitch 576): part[block] = sum D^2,
+// S <- 4 * w * D  (the factor of dYhat = (dS + dS^T) Yhat for the symmetric D)
+hipError_t launch_ssc_loss_grad(float* S, const float* cat0, int imgs, int N, float w, double* part, int* nparts,
+                                hipStream_t stream);
+// dY = (dYhat - Yhat <Yhat, dYhat>) / norm per channel vector, written NHWC: out[(n*49+p)*out_pitch + out_coff + c]
+hipError_t launch_loss_ch_finish(const float* dYht, const float* Yht, const float* ynorm, float* out, int out_pitch,
+                                 int out_coff, int imgs, hipStream_t stream);
+// ss_space term, one block per image: Z = feat_space rows (pitch/coff), target ss0[n % N] stored as bufS[(n0*49+j)*576+512+i];
+// part[n] = sum D^2; dZ -> out[(n*49+i)*out_pitch + out_coff + c]
+hipError_t launch_ss_space_loss(const float* feat, int pitch, int coff, const float* bufS, int imgs, int N, float w,
+                                double* part, float* out, int out_pitch, int out_coff, hipStream_t stream);
+// identity (all rows) and triplet (occluded rows, n >= N) terms on f_new[2N][512] with the encoder embeddings f_enc[2N][512]:
+// df[2N][512]; part[n] = identity sum of squares, part[2N + n] = relu(pos - neg + margin)
+hipError_t launch_vec_losses(const float* f_new, const float* f_enc, int N, float w_identity, float w_triplet, float margin,
+                             float* df, double* part, hipStream_t stream);
+// CosFace cross entropy per row of cos[2N][cos_pitch]: dcos = s * w_row * (softmax - onehot) (pad columns zero);
+// part[n] = -log softmax[label]; hit[n] = (argmax_k cos == label)
+hipError_t launch_ce_loss(const float* cosv, int cos_pitch, const int* label, int N, int classes, float s, float m,
+                          float w_non, float w_ocl, float* dcos, double* part, int* hit, hipStream_t stream);
+// out[0..3] = the four weighted loss items, out[4] = accuracy of the occluded half; fixed summation order
+struct LossParts { const double *ss_space, *ss_channel, *vec, *ce; const int* hit; int n_ssc; };
+hipError_t launch_loss_finish(LossParts p, int N, LossCoef c, float* out, hipStream_t stream);
+
 // one state_dict entry between the torch layout (`natural`) and the kernel layout (`native`), both on the device
 hipError_t launch_seg_convert(float* native, float* natural, size_t n, int kind, int d1, int p1, int colperm, int to_native,
                               hipStream_t stream);

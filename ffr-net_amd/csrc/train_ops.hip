@@ -826,4 +826,363 @@ hipError_t launch_seg_convert(float* native, float* natural, size_t n, int kind,
     return hipGetLastError();
 }
 
+// =====================================================================================================
+// The four loss items of Trainer.backward (models/trainer.py:154-178) with their gradients wrt the RecNet outputs
+//   item 0: ((mse(ss_space(F), ss_space(space_non)) + mse(.., space_ocl)) / 2 + (same for ss_channel)) / 2
+//   item 1: TripletLoss(f_ocl, f_enc_non, f_enc_ocl), margin 0.1          (models/trainer.py:38-43)
+//   item 2: (mse(f_non, f_enc_non) + mse(f_ocl, f_enc_non)) / 2
+//   item 3: CE(pred_loss_non) / (1e-8 + w3) + CE(pred_loss_ocl)
+// Partial sums are doubles, one per block / row, added in index order by k_loss_finish.
+
+// block per (image, 32-channel group): the channel vectors of a NHWC slice, normalised over the 49 positions
+__global__ __launch_bounds__(256) void k_loss_ch_prep(const float* __restrict__ feat, int pitch, int coff,
+                                                     float* __restrict__ Yht, float* __restrict__ Yh_nhwc,
+                                                     float* __restrict__ ynorm) {
+    __shared__ float t[49][33];
+    __shared__ float inv[32];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int p = ty; p < 49; p += 8) t[p][tx] = feat[((size_t)n * 49 + p) * pitch + coff + c0 + tx];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int p = 0; p < 49; ++p) s += t[p][threadIdx.x] * t[p][threadIdx.x];
+        const float d = fmaxf(sqrtf(s), 1e-12f);
+        inv[threadIdx.x] = 1.0f / d;
+        ynorm[(size_t)n * 512 + c0 + threadIdx.x] = d;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        Yht[((size_t)n * 512 + c0 + c) * 64 + p] = p < 49 ? t[p][c] * inv[c] : 0.f;
+    }
+    for (int p = ty; p < 64; p += 8) Yh_nhwc[((size_t)n * 64 + p) * 512 + c0 + tx] = p < 49 ? t[p][tx] * inv[tx] : 0.f;
+}
+
+hipError_t launch_loss_ch_prep(const float* feat, int pitch, int coff, float* Yht, float* Yh_nhwc, float* ynorm, int imgs,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(k_loss_ch_prep, dim3(16, imgs), dim3(256), 0, stream, feat, pitch, coff, Yht, Yh_nhwc, ynorm);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ double block_sum_double(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+
+// one block per (image, 8 rows of S): 8 * 512 / 4 = 1024 float4 -> 4 per thread
+__global__ __launch_bounds__(256) void k_ssc_loss_grad(float* __restrict__ S, const float* __restrict__ cat0, int N, float w4,
+                                                      double* __restrict__ part) {
+    __shared__ double sh[4];
+    const int n = blockIdx.y, r0 = blockIdx.x * 8;
+    const int n0 = n % N;
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = q * 256 + threadIdx.x;
+        const int r = r0 + (i >> 7), c = (i & 127) * 4;
+        float* sp = S + ((size_t)n * 512 + r) * 512 + c;
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(sp);
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(cat0 + ((size_t)n0 * 512 + r) * 576 + c);
+        const f32x4 d = sv - tv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += (double)d[e] * (double)d[e];
+        *reinterpret_cast<f32x4*>(sp) = d * w4;
+    }
+    const double tot = block_sum_double(acc, sh);
+    if (threadIdx.x == 0) part[(size_t)n * 64 + blockIdx.x] = tot;
+}
+
+hipError_t launch_ssc_loss_grad(float* S, const float* cat0, int imgs, int N, float w, double* part, int* nparts,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(k_ssc_loss_grad, dim3(64, imgs), dim3(256), 0, stream, S, cat0, N, 4.0f * w, part);
+    *nparts = imgs * 64;
+    return hipGetLastError();
+}
+
+// block per (image, 32-channel group)
+__global__ __launch_bounds__(256) void k_loss_ch_finish(const float* __restrict__ dYht, const float* __restrict__ Yht,
+                                                       const float* __restrict__ ynorm, float* __restrict__ out, int out_pitch,
+                                                       int out_coff) {
+    __shared__ float g[32][65];
+    __shared__ float dots[32];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) {
+        const int c = i >> 6, p = i & 63;
+        g[c][p] = dYht[((size_t)n * 512 + c0 + c) * 64 + p];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        const float* y = Yht + ((size_t)n * 512 + c0 + c) * 64;
+        float s = 0.f;
+        for (int p = 0; p < 49; ++p) s += y[p] * g[c][p];
+        dots[c] = s;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float inv = 1.0f / ynorm[(size_t)n * 512 + c0 + tx];
+    for (int p = ty; p < 49; p += 8) {
+        const float yh = Yht[((size_t)n * 512 + c0 + tx) * 64 + p];
+        out[((size_t)n * 49 + p) * out_pitch + out_coff + c0 + tx] = (g[tx][p] - yh * dots[tx]) * inv;
+    }
+}
+
+hipError_t launch_loss_ch_finish(const float* dYht, const float* Yht, const float* ynorm, float* out, int out_pitch,
+                                 int out_coff, int imgs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_loss_ch_finish, dim3(16, imgs), dim3(256), 0, stream, dYht, Yht, ynorm, out, out_pitch, out_coff);
+    return hipGetLastError();
+}
+
+// one block per image: position vectors Z[49][512] normalised over the channels, 49x49 Gram, its gradient
+__global__ __launch_bounds__(256) void k_ss_space_loss(const float* __restrict__ feat, int pitch, int coff,
+                                                      const float* __restrict__ bufS, int N, float w4,
+                                                      double* __restrict__ part, float* __restrict__ out, int out_pitch,
+                                                      int out_coff) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Zh = lds;                 // [49][516]
+    float* E = lds + 49 * 516;       // [49][50]
+    float* nrm = E + 49 * 50;        // [49]
+    __shared__ double shd[4];
+    __shared__ float shf[4];
+    const int n = blockIdx.x, n0 = n % N;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // rows -> LDS, one wave per row in turn
+    for (int i = wv; i < 49; i += 4) {
+        const float* z = feat + ((size_t)n * 49 + i) * pitch + coff;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(z + lane * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(z + lane * 8 + 4);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += a[e] * a[e] + b[e] * b[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float d = fmaxf(sqrtf(s), 1e-12f);
+        *reinterpret_cast<f32x4*>(Zh + i * 516 + lane * 8) = a / d;
+        *reinterpret_cast<f32x4*>(Zh + i * 516 + lane * 8 + 4) = b / d;
+        if (lane == 0) nrm[i] = d;
+    }
+    __syncthreads();
+    // Gram entries, D = S - S0, E = 4 w D
+    double acc = 0.0;
+    for (int o = tid; o < 49 * 49; o += 256) {
+        const int i = o / 49, j = o - i * 49;
+        const f32x4* a = reinterpret_cast<const f32x4*>(Zh + i * 516);
+        const f32x4* b = reinterpret_cast<const f32x4*>(Zh + j * 516);
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 128; ++c) s4 += a[c] * b[c];
+        const float sv = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        const float d = sv - bufS[((size_t)n0 * 49 + j) * 576 + 512 + i];
+        acc += (double)d * (double)d;
+        E[i * 50 + j] = d * w4;
+    }
+    const double tot = block_sum_double(acc, shd);
+    if (tid == 0) part[n] = tot;
+    __syncthreads();
+    // dZhat[i][c] = sum_j E[i][j] Zhat[j][c]; thread owns channels c = tid and tid + 256
+    for (int i = 0; i < 49; ++i) {
+        float g0 = 0.f, g1 = 0.f;
+        for (int j = 0; j < 49; ++j) {
+            const float e = E[i * 50 + j];
+            g0 += e * Zh[j * 516 + tid];
+            g1 += e * Zh[j * 516 + tid + 256];
+        }
+        const float z0 = Zh[i * 516 + tid], z1 = Zh[i * 516 + tid + 256];
+        float dot = g0 * z0 + g1 * z1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        if (lane == 0) shf[wv] = dot;
+        __syncthreads();
+        dot = (shf[0] + shf[1]) + (shf[2] + shf[3]);
+        const float inv = 1.0f / nrm[i];
+        float* o = out + ((size_t)n * 49 + i) * out_pitch + out_coff;
+        o[tid] = (g0 - z0 * dot) * inv;
+        o[tid + 256] = (g1 - z1 * dot) * inv;
+        __syncthreads();
+    }
+}
+
+static const size_t SS_SPACE_LDS = (size_t)(49 * 516 + 49 * 50 + 64) * 4;
+
+hipError_t launch_ss_space_loss(const float* feat, int pitch, int coff, const float* bufS, int imgs, int N, float w,
+                                double* part, float* out, int out_pitch, int out_coff, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_ss_space_loss, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)SS_SPACE_LDS);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_ss_space_loss, dim3(imgs), dim3(256), SS_SPACE_LDS, stream, feat, pitch, coff, bufS, N, 4.0f * w, part,
+                       out, out_pitch, out_coff);
+    return hipGetLastError();
+}
+
+// one wave per row n of f_new[2N][512]
+__global__ __launch_bounds__(256) void k_vec_losses(const float* __restrict__ f_new, const float* __restrict__ f_enc, int N,
+                                                   float w_identity, float w_triplet, float margin, float* __restrict__ df,
+                                                   double* __restrict__ part) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= 2 * N) return;
+    const int n0 = n % N;
+    f32x4 x[2], en[2], g[2];
+    float ss = 0.f, xx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        x[q] = *reinterpret_cast<const f32x4*>(f_new + (size_t)n * 512 + lane * 8 + 4 * q);
+        en[q] = *reinterpret_cast<const f32x4*>(f_enc + (size_t)n0 * 512 + lane * 8 + 4 * q);
+        const f32x4 d = x[q] - en[q];
+        g[q] = d * w_identity;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ss += d[e] * d[e]; xx += x[q][e] * x[q][e]; }
+    }
+    ss = wave_sum(ss);
+    xx = wave_sum(xx);
+    if (lane == 0) part[n] = (double)ss;
+    float hinge = 0.f;
+    if (n >= N) {
+        // x = f_ocl, y = f_enc_non (en), z = f_enc_ocl
+        f32x4 z[2];
+        float yy = 0.f, zz = 0.f, xy = 0.f, xz = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            z[q] = *reinterpret_cast<const f32x4*>(f_enc + (size_t)n * 512 + lane * 8 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                yy += en[q][e] * en[q][e]; zz += z[q][e] * z[q][e];
+                xy += x[q][e] * en[q][e]; xz += x[q][e] * z[q][e];
+            }
+        }
+        yy = wave_sum(yy); zz = wave_sum(zz); xy = wave_sum(xy); xz = wave_sum(xz);
+        const float nx = fmaxf(sqrtf(xx), 1e-12f), ny = fmaxf(sqrtf(yy), 1e-12f), nz = fmaxf(sqrtf(zz), 1e-12f);
+        const float pos = 1.f - xy / (nx * ny), neg = 1.f - xz / (nx * nz);
+        hinge = pos - neg + margin;
+        if (hinge > 0.f) {
+            // d/dxhat = w (-yhat + zhat); dx = (dxhat - xhat <xhat, dxhat>) / |x|
+            const float dot = w_triplet * (-xy / (nx * ny) + xz / (nx * nz));     // <xhat, dxhat>
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dxh = w_triplet * (-en[q][e] / ny + z[q][e] / nz);
+                    g[q][e] += (dxh - (x[q][e] / nx) * dot) / nx;
+                }
+        } else {
+            hinge = 0.f;
+        }
+    }
+    if (lane == 0) part[2 * N + n] = (double)hinge;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<f32x4*>(df + (size_t)n * 512 + lane * 8 + 4 * q) = g[q];
+}
+
+hipError_t launch_vec_losses(const float* f_new, const float* f_enc, int N, float w_identity, float w_triplet, float margin,
+                             float* df, double* part, hipStream_t stream) {
+    hipLaunchKernelGGL(k_vec_losses, dim3((2 * N + 3) / 4), dim3(256), 0, stream, f_new, f_enc, N, w_identity, w_triplet, margin,
+                       df, part);
+    return hipGetLastError();
+}
+
+// one block per row: logits z_k = s (cos_k - m [k == label]); softmax cross entropy and its gradient wrt cos
+__global__ __launch_bounds__(256) void k_ce_loss(const float* __restrict__ cosv, int cos_pitch, const int* __restrict__ label,
+                                                int N, int classes, float s, float m, float w_non, float w_ocl,
+                                                float* __restrict__ dcos, double* __restrict__ part, int* __restrict__ hit) {
+    __shared__ float shm[4];
+    __shared__ int shi[4];
+    __shared__ double shd[4];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lab = label[n];
+    const float* row = cosv + (size_t)n * cos_pitch;
+    // max logit and argmax of the cosine (first index on ties, as torch.max)
+    float mx = -3.0e38f, cmx = -3.0e38f;
+    int arg = 0x7fffffff;
+    for (int k = tid; k < classes; k += 256) {
+        const float c = row[k];
+        const float z = s * (k == lab ? c - m : c);
+        mx = fmaxf(mx, z);
+        if (c > cmx) { cmx = c; arg = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float oc = __shfl_xor(cmx, o);
+        const int oa = __shfl_xor(arg, o);
+        if (oc > cmx || (oc == cmx && oa < arg)) { cmx = oc; arg = oa; }
+    }
+    if (lane == 0) shm[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+    __syncthreads();
+    if (lane == 0) { shm[wv] = cmx; shi[wv] = arg; }
+    __syncthreads();
+    if (tid == 0) {
+        float bc = shm[0]; int ba = shi[0];
+        for (int q = 1; q < 4; ++q) if (shm[q] > bc || (shm[q] == bc && shi[q] < ba)) { bc = shm[q]; ba = shi[q]; }
+        hit[n] = (ba == lab) ? 1 : 0;
+    }
+    double se = 0.0;
+    for (int k = tid; k < classes; k += 256) {
+        const float c = row[k];
+        se += (double)__expf(s * (k == lab ? c - m : c) - mx);
+    }
+    __syncthreads();
+    const double tot = block_sum_double(se, shd);
+    __shared__ float lse_s;
+    if (tid == 0) {
+        const float zl = s * (row[lab] - m);
+        part[n] = (double)mx + log(tot) - (double)zl;
+        lse_s = (float)((double)mx + log(tot));
+    }
+    __syncthreads();
+    const float lse = lse_s;
+    const float wr = s * (n < N ? w_non : w_ocl);
+    for (int k = tid; k < cos_pitch; k += 256) {
+        float g = 0.f;
+        if (k < classes) {
+            const float c = row[k];
+            const float p = __expf(s * (k == lab ? c - m : c) - lse);
+            g = wr * (p - (k == lab ? 1.f : 0.f));
+        }
+        dcos[(size_t)n * cos_pitch + k] = g;
+    }
+}
+
+hipError_t launch_ce_loss(const float* cosv, int cos_pitch, const int* label, int N, int classes, float s, float m,
+                          float w_non, float w_ocl, float* dcos, double* part, int* hit, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ce_loss, dim3(2 * N), dim3(256), 0, stream, cosv, cos_pitch, label, N, classes, s, m, w_non, w_ocl, dcos,
+                       part, hit);
+    return hipGetLastError();
+}
+
+// single block; every sum in index order
+__global__ __launch_bounds__(64) void k_loss_finish(LossParts p, int N, LossCoef c, float* out) {
+    if (threadIdx.x != 0) return;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 2 * N; ++i) a += p.ss_space[i];
+    for (int i = 0; i < p.n_ssc; ++i) b += p.ss_channel[i];
+    out[0] = (float)(a * (double)c.w_ss_space + b * (double)c.w_ss_channel);
+    double t = 0.0, id = 0.0;
+    for (int i = 0; i < 2 * N; ++i) id += p.vec[i];
+    for (int i = N; i < 2 * N; ++i) t += p.vec[2 * N + i];
+    out[1] = (float)(t * (double)c.w_triplet);
+    out[2] = (float)(id * (double)c.w_identity);
+    double cn = 0.0, co = 0.0;
+    int hits = 0;
+    for (int i = 0; i < N; ++i) cn += p.ce[i];
+    for (int i = N; i < 2 * N; ++i) { co += p.ce[i]; hits += p.hit[i]; }
+    out[3] = (float)(cn * (double)c.w_ce_non + co * (double)c.w_ce_ocl);
+    out[4] = (float)hits / (float)N;
+}
+
+hipError_t launch_loss_finish(LossParts p, int N, LossCoef c, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, stream, p, N, c, out);
+    return hipGetLastError();
+}
+
 }  // namespace ffr

@@ -83,6 +83,9 @@ SYMBOLS = [
     ('ffr_train_option', C.c_int, [_P, C.c_char_p, C.c_int]),
     ('ffr_train_export', C.c_int, [_P, C.c_int, C.c_char_p, _P, _P]),
     ('ffr_train_import', C.c_int, [_P, C.c_int, C.c_char_p, _P, _P]),
+    ('ffr_train_losses', C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), _P, _P]),
+    ('ffr_train_backward_losses', C.c_int, [_P, C.c_int, _P]),
+    ('ffr_train_iteration', C.c_int, [_P, _P, _P, _P, C.c_int, C.POINTER(C.c_double), _P, _P]),
 ]
 
 
@@ -446,6 +449,34 @@ class Engine(object):
         v = value.detach().contiguous().float()
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_train_import(self._h, self._WHICH[which], key.encode(), _ptr(v), self._stream()))
+
+    def train_losses(self, f_enc, loss_weight=(1, 1, 1, 1), slot=0):
+        """The four weighted loss items + accuracy (device tensor [5]) of the forward in `slot` (G = 2)."""
+        _check_dev(f_enc, 'f_enc')
+        out = torch.empty(5, device=f_enc.device, dtype=torch.float32)
+        lw = (C.c_double * 4)(*[float(x) for x in loss_weight])
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_losses(self._h, slot, _ptr(f_enc.contiguous()), lw, _ptr(out), self._stream()))
+        return out
+
+    def train_backward_losses(self, slot=0):
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_backward_losses(self._h, slot, self._stream()))
+
+    def train_iteration(self, img_non, img_ocl, label, loss_weight=(1, 1, 1, 1)):
+        """Encoder + RecNet train forward + losses + zero_grad + backward in one native call -> device tensor [5]."""
+        _check_dev(img_non, 'img_non')
+        _check_dev(img_ocl, 'img_ocl')
+        n = img_non.size(0)
+        if tuple(img_non.shape[1:]) != (3, 112, 112) or img_ocl.shape != img_non.shape:
+            raise RuntimeError('ffrnet_amd: training images must be [N,3,112,112] pairs')
+        lab = label.to(img_non.device, torch.int32).contiguous()
+        out = torch.empty(5, device=img_non.device, dtype=torch.float32)
+        lw = (C.c_double * 4)(*[float(x) for x in loss_weight])
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_train_iteration(self._h, _ptr(img_non.contiguous()), _ptr(img_ocl.contiguous()), _ptr(lab), n,
+                                                  lw, _ptr(out), self._stream()))
+        return out
 
     def train_option(self, name, value):
         self._ck(self.lib.ffr_train_option(self._h, name.encode(), int(value)))

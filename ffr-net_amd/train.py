@@ -8,10 +8,11 @@
                                                            flat fp32 gradient buffer (RCCL over xGMI); BatchNorm
                                                            statistics stay per replica, as in the reference
 
-What runs where: encoder forward, RecNet forward (7-tuple) and the whole RecNet backward, gradient clipping
-and Adam are native (ffr-net_amd/csrc/train*.{cpp,hip}, wgrad.hip).  The four loss items are evaluated by
-`trainer_losses` below on the device with torch ops on the (small) outputs, and their partial derivatives
-with respect to the 7-tuple are handed to the native backward.  There is no CPU path.
+What runs where: everything of an iteration is native (ffr-net_amd/csrc/train*.{cpp,hip}, wgrad.hip): encoder
+forward, RecNet forward, the four loss items and their gradients, the whole RecNet backward, gradient clipping
+and Adam; torch only carries the device buffers and the all-reduce.  `trainer_losses` below restates the loss
+items with torch ops on the device: `NativeTrainer.step_torch_losses` uses it as the cross-check of the native
+loss kernels.  There is no CPU path.
 """
 import torch
 import torch.nn.functional as F
@@ -124,7 +125,19 @@ class NativeTrainer(object):
             dist.broadcast(self._params, src, group=self.group)
 
     def step(self, img_non, img_ocl, label):
-        """Trainer.set_input + forward + optimizer_parameters.  Returns the four loss values (floats, device sync)."""
+        """Trainer.set_input + forward + optimizer_parameters (models/trainer.py:131-187), everything native:
+        one launch-only call up to the gradients (ffr_train_iteration), the gradient exchange, clip + Adam.
+        Returns the four weighted loss items as a device tensor view (no host sync)."""
+        out5 = self.engine.train_iteration(img_non, img_ocl, label, self.loss_weight)
+        average_gradients(self._grads, self.group)
+        self.engine.train_adam_step(self.lr, self.betas, 1e-8, self.weight_decay, self.clip_value)
+        self.loss_items = [out5[i] for i in range(4)]
+        self.accuracy = out5[4]
+        return self.loss_items
+
+    def step_torch_losses(self, img_non, img_ocl, label):
+        """The same iteration with the four loss items evaluated by torch ops (`trainer_losses`) and their autograd
+        cotangents handed to ffr_train_backward: the cross-check of the native loss kernels."""
         eng = self.engine
         n = img_non.size(0)
         with torch.no_grad():

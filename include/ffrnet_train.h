@@ -82,6 +82,22 @@ int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const floa
                        const float* d_pred_label, const float* d_M_space, const float* d_M_channel,
                        const float* d_feat_space, const float* d_feat_channel, void* stream);
 
+/* The four weighted loss items of Trainer.backward (models/trainer.py:154-178: self-similarity MSE, triplet,
+ * identity MSE, CosFace cross entropy) for the forward recorded in `slot`, which must hold the clean half followed
+ * by the occluded half (G = 2), and their gradients with respect to the RecNet outputs, kept inside the handle.
+ * f_enc [2N,512]: the encoder embeddings of both halves (device).  loss_weight: 4 doubles (host), run.py:16.
+ * out5 (device, may be NULL): the four items and the accuracy of the occluded half (trainer.py:147-151).        */
+int ffr_train_losses(ffr_handle* h, int slot, const float* f_enc, const double* loss_weight, float* out5, void* stream);
+/* ffr_train_backward with the gradients ffr_train_losses left in the handle */
+int ffr_train_backward_losses(ffr_handle* h, int slot, void* stream);
+
+/* One iteration up to the gradients, train.py:46-54 without the optimiser step, in ONE launch-only call: encoder
+ * (frozen, eval) on the clean and the occluded images [N,3,112,112] (NCHW fp32, device), RecNet train-mode forward,
+ * the four loss items, zero_grad, backward.  The caller averages the flat gradient buffer over the ranks (if any)
+ * and calls ffr_train_adam_step.  label int32 [N] (device); out5 as for ffr_train_losses.                      */
+int ffr_train_iteration(ffr_handle* h, const float* img_non, const float* img_ocl, const int32_t* label, int N,
+                        const double* loss_weight, float* out5, void* stream);
+
 /* clip_grad_value_(clip_value) (<= 0: no clipping) followed by one torch.optim.Adam step on every
  * parameter (models/trainer.py:182-187); one fused elementwise launch over the flat buffers.           */
 int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -94,7 +110,7 @@ int ffr_train_option(ffr_handle* h, const char* name, int value);
 
 /* Test hook: the first n floats of a named intermediate buffer of context `slot` (forward activations:
  * "X" "cat" "h1pre" "h1" "t2" "h2pre" "h3pre" "Mc" "raw" "Xht"; backward scratch: "d32a" "d32b" "dMc" "dt"
- * "dBufM" "dF" "dms") copied to host memory, in the kernel layouts.  Synchronises the device.          */
+ * "dBufM" "dF" "dms"; loss gradients: "df_ext" "dcos" "extM") copied to host memory, in the kernel layouts.  Synchronises the device.          */
 int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_out, size_t n);
 
 #ifdef __cplusplus

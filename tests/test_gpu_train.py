@@ -101,7 +101,7 @@ def build_train_case(specs, smooth=False):
     leaf_ocl = [o.detach().clone().requires_grad_(True) for o in out_ocl]
     items_l = OT.trainer_losses(leaf_non, leaf_ocl, fm_non, fe_non, fe_ocl, label)
     og = torch.autograd.grad(sum(items_l), leaf_non + leaf_ocl, allow_unused=True)
-    return dict(sd_r=sd_r, fm=torch.cat([fm_non, fm_ocl]), label=torch.cat([label, label]), out_non=out_non,
+    return dict(sd_r=sd_r, f_enc=torch.cat([fe_non, fe_ocl]), fm=torch.cat([fm_non, fm_ocl]), label=torch.cat([label, label]), out_non=out_non,
                 out_ocl=out_ocl, out_grads=og, param_grads=pg, running=running, keys=keys,
                 losses=[float(l.detach()) for l in items])
 
@@ -269,6 +269,11 @@ def test_native_trainer_step_matches_reference(specs, golden_dir):
     tr2 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
     items2 = tr2.step(non.cuda(), ocl.cuda(), label.cuda())
     assert np.allclose(np.array([float(l) for l in items2]), g8['losses'], rtol=1e-4)
+    # the same iteration with the loss items evaluated by torch ops instead of the native loss kernels
+    tr3 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
+    items3 = tr3.step_torch_losses(non.cuda(), ocl.cuda(), label.cuda())
+    assert np.allclose(np.array([float(l) for l in items3]), np.array([float(l) for l in items2]), rtol=1e-4)
+    assert float(tr3.accuracy) == float(tr2.accuracy)
     for k in keys:
         l2 = ((eng.train_get(k, 'grad') - direct[k]).norm() / direct[k].norm().clamp_min(1e-30)).item()
         assert l2 < 1e-1, (k, l2)      # kink noise, see test_train_backward_kink_free_network_both_modes
@@ -353,3 +358,39 @@ def test_recnet_shell_train_branch_two_iterations(specs):
             assert int(sd_m[k]) == 4
         elif k.endswith(('running_mean', 'running_var')):
             assert rel(sd_m[k], v) < 1e-4, k
+
+
+def test_native_loss_items_and_their_gradients(engine, train_case):
+    """ffr_train_losses: the four loss items of Trainer.backward (models/trainer.py:154-178) and their partial
+    derivatives wrt the RecNet outputs, against the oracle's values and autograd cotangents."""
+    tc = train_case
+    engine.train_init(tc['sd_r'])
+    engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
+    out5 = engine.train_losses(tc['f_enc'].cuda()).cpu()
+    assert np.allclose(out5[:4].numpy(), tc['losses'], rtol=1e-4), (out5, tc['losses'])
+    acc = (tc['out_ocl'][2].detach().argmax(1) == tc['label'][:4]).float().mean().item()
+    assert float(out5[4]) == acc
+    og = tc['out_grads']
+    df = engine.train_debug('df_ext', (8, 512))
+    assert rel(df, torch.cat([og[0], og[7]])) < 1e-4
+    dcos = engine.train_debug('dcos', (8, 10624))
+    assert rel(dcos[:, :10575], 30.0 * torch.cat([og[1], og[8]])) < 1e-4
+    assert dcos[:, 10575:].abs().max() == 0
+    ext = engine.train_debug('extM', (8 * 49, 1024)).reshape(8, 49, 1024)
+    d_fs = torch.cat([og[5], og[12]]).reshape(8, 512, 49).permute(0, 2, 1)
+    d_fc = torch.cat([og[6], og[13]]).reshape(8, 512, 49).permute(0, 2, 1)
+    assert rel(ext[:, :, :512], d_fs) < 2e-4
+    assert rel(ext[:, :, 512:], d_fc) < 2e-4
+    # and the backward fed by them gives the gradients of the direct-mode reference run
+    engine.train_option('winograd', 0)
+    engine.train_init(tc['sd_r'])
+    engine.train_option('winograd', 0)
+    engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
+    engine.train_losses(tc['f_enc'].cuda())
+    engine.train_zero_grad()
+    engine.train_backward_losses()
+    torch.cuda.synchronize()
+    kink = {'Conv4Channel.0.weight': 5e-3, 'Conv4Channel.0.bias': 5e-3}
+    for k in tc['keys']:
+        ref = tc['param_grads'][k]
+        assert rel(engine.train_get(k, 'grad'), ref) < kink.get(k, 2e-4), k
