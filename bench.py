@@ -91,6 +91,50 @@ def cpu_baseline(sd_e, sd_r, budget_s=12.0):
                                                      os.cpu_count() or 0)}
 
 
+def train_workload(args, world, rank, local, dist):
+    """Secondary workload (SURVEY 8 row N3 / BASELINE configs[4]): whole training iterations through NativeTrainer."""
+    dev = torch.device('cuda', local)
+    spec_e, spec_r = state_dict_specs()
+    eng = ffrnet_amd.Engine(local)
+    eng.load_encoder(synth.synth_state_dict(spec_e))
+    tr = ffrnet_amd.NativeTrainer(eng, synth.synth_state_dict(spec_r), lr=1e-3)
+    tr.broadcast_params(0)
+    B = args.batch if args.batch != 256 else 128           # pairs per GPU (1024 pairs over 8 GPUs)
+    non, ocl, label = synth.synth_train_batch(B, seed=500 + rank)
+    non, ocl, label = non.to(dev), ocl.to(dev), label.to(dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(non, ocl, label)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items = tr.step(non, ocl, label)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert all(torch.isfinite(l) for l in items)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training image pairs/sec (frozen IR-SE50 encoder + RecNet forward/backward + CosFace head + clip + Adam)',
+            'value': round(world * B * args.steps / dt, 1), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[4]: training step, %d pairs per GPU, 112x112x3 fp32' % B,
+                       'pairs_per_gpu': B, 'global_pairs': world * B,
+                       'parallelism': 'data parallel x%d, one RCCL all-reduce of the flat fp32 gradient buffer per step' % world},
+            'roofline': None, 'cpu_baseline': None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,6 +143,10 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--workload', choices=('embed', 'train'), default='embed',
+                    help="embed (default): BASELINE.json's metric; train: the RecNet training iteration of configs[4] "
+                         '(128 image pairs per GPU unless --batch is given), data parallel with one all-reduce of the '
+                         'flat gradient buffer')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -116,6 +164,8 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world,
                                 device_id=torch.device('cuda', local))
     dev = torch.device('cuda', local)
+    if args.workload == 'train':
+        return train_workload(args, world, rank, local, dist)
 
     spec_e, spec_r = state_dict_specs()
     sd_e = synth.synth_state_dict(spec_e)

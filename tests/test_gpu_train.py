@@ -394,3 +394,32 @@ def test_native_loss_items_and_their_gradients(engine, train_case):
     for k in tc['keys']:
         ref = tc['param_grads'][k]
         assert rel(engine.train_get(k, 'grad'), ref) < kink.get(k, 2e-4), k
+
+
+def test_training_full_size_properties(specs):
+    """BASELINE configs[4] per-GPU shape (128 pairs per iteration), where the oracle is too slow: properties.
+    Bitwise reproducibility of a whole iteration, direct vs Winograd mode agree on the loss items, a few Adam steps
+    on a fixed batch lower the total loss, everything stays finite."""
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    non, ocl, label = synth.synth_train_batch(128, seed=77)
+    non, ocl, label = non.cuda(), ocl.cuda(), label.cuda()
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    first = []
+    for mode in (1, 1, 0):
+        tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
+        eng.train_option('winograd', mode)
+        items = torch.stack(tr.step(non, ocl, label)).cpu()
+        first.append((items, tr.flat_grads.clone()))
+    assert torch.equal(first[0][0], first[1][0]) and torch.equal(first[0][1], first[1][1])       # same mode: bitwise
+    assert torch.allclose(first[0][0], first[2][0], rtol=2e-4)                                   # Winograd vs direct
+    l2 = ((first[0][1] - first[2][1]).norm() / first[2][1].norm()).item()
+    assert l2 < 2e-2, l2          # whole flat gradient, kink noise included (256-image batch)
+    tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
+    totals = []
+    for _ in range(6):
+        totals.append(float(torch.stack(tr.step(non, ocl, label)).sum()))
+    assert all(np.isfinite(totals)) and totals[-1] < totals[0], totals
+    assert torch.isfinite(tr.flat_params).all()
+    assert 0.0 <= float(tr.accuracy) <= 1.0
