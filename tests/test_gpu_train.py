@@ -423,3 +423,29 @@ def test_training_full_size_properties(specs):
     assert all(np.isfinite(totals)) and totals[-1] < totals[0], totals
     assert torch.isfinite(tr.flat_params).all()
     assert 0.0 <= float(tr.accuracy) <= 1.0
+
+
+@pytest.mark.parametrize('n', [1, 3])
+def test_train_forward_small_and_odd_batches(engine, specs, n):
+    """Edge batches: one image per group (BatchNorm statistics over 49 positions only) and an odd count."""
+    import ffr_oracle_train as OT
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    g = torch.Generator().manual_seed(40 + n)
+    fm = torch.randn(2 * n, 512, 7, 7, generator=g) * 0.6
+    label = torch.randint(0, 10575, (n,), generator=g)
+    keys = OT.trainable_keys(sd_r)
+    params = {k: sd_r[k] for k in keys}
+    running = {k: v.clone() for k, v in sd_r.items() if k not in params}
+    with torch.no_grad():
+        ref = [OT.recnet_train_forward(params, fm[i * n:(i + 1) * n], label, running) for i in range(2)]
+    engine.train_init(sd_r)
+    outs = engine.train_forward(fm.cuda(), torch.cat([label, label]).cuda(), groups=2)
+    torch.cuda.synchronize()
+    for gi in range(2):
+        for nm, o, r in zip(NAMES, outs, ref[gi]):
+            got = o[gi * n:(gi + 1) * n].cpu()
+            assert rel(got, r.reshape(got.shape)) < 2e-4, (n, gi, nm)
+    sd_after = engine.train_state_dict()
+    for k, v in running.items():
+        if k.endswith(('running_mean', 'running_var')):
+            assert rel(sd_after[k], v) < 2e-4, k
