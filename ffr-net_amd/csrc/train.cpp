@@ -82,7 +82,7 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
                            L.gslope, accumulate, s.dy, s.part, st));
     const long long T = (long long)G * N * 4;          // 2x2 tiles of 4x4 outputs per 7x7 map
     const bool wino_w = s.wino && L.cin_pad >= 128 && w.winoV && (size_t)36 * T * L.cin_pad <= w.wino_cap &&
-                        (size_t)36 * T * L.cout_pad <= w.wino_cap && (size_t)36 * L.cout_pad * L.cin_pad <= s.slab_floats;
+                        (size_t)36 * T * L.cout_pad <= w.wino_cap && s.U && (size_t)36 * L.cout_pad * L.cin_pad <= s.U_floats;
     if (wino_w) {
         // weight gradient in the Winograd domain: dU[xi] = dM[xi]^T V[xi] (36 TN GEMMs over the tiles), dW += G^T dU G
         HIPCK(h, launch_wino_in(sv.x, w.winoV, G * N, 7, 7, sv.x_pitch, L.cin_pad, 1, st));
@@ -90,8 +90,9 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
         WgradArgs a{};
         a.dy = w.winoM; a.x = w.winoV; a.zero = h->zero; a.rows = (int)T; a.H = 1; a.W = 1; a.x_pitch = L.cin_pad;
         a.dy_pitch = L.cout_pad; a.cin_pad = L.cin_pad; a.taps = 1; a.pad_mode = 0; a.cout_pad = L.cout_pad;
-        HIPCK(h, launch_wgrad_batched(a, s.slabs, 36, T * L.cout_pad, T * L.cin_pad, st));
-        HIPCK(h, launch_wino_dweights(s.slabs, L.gw, L.cout_pad, L.cin_pad, accumulate, st));
+        // dU in the U scratch (free until the data gradient re-derives its weights), split-K slabs in s.slabs
+        HIPCK(h, launch_wgrad_batched(a, s.U, 36, T * L.cout_pad, T * L.cin_pad, s.slabs, s.slab_floats, st));
+        HIPCK(h, launch_wino_dweights(s.U, L.gw, L.cout_pad, L.cin_pad, accumulate, st));
     } else {
         WgradArgs a{};
         a.dy = s.dy; a.x = sv.x; a.zero = h->zero; a.rows = rows; a.H = 7; a.W = 7; a.x_pitch = sv.x_pitch;

@@ -18,15 +18,16 @@ struct WgradArgs {
     float* out;           // set by the launcher: split-K slabs [splits][cout_pad][Ng]
     int rows, H, W, x_pitch, dy_pitch, cin_pad, taps, pad_mode, cout_pad;
     int Ng, mtiles, ntiles, nkt, splits, kt_per_split;    // set by the launcher
-    int nbatch; long long dy_bstride, x_bstride, out_bstride;   // set by the launcher (batched form)
+    int nbatch; long long dy_bstride, x_bstride, out_bstride, split_stride;   // set by the launcher
 };
 // grad[cout_pad][taps*cin_pad] (+)= dy^T * gather(x); scratch holds the split-K slabs
 hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch, size_t scratch_floats,
                         hipStream_t stream);
 
-// out[b][cout_pad][cin_pad] = dy[b]^T x[b] for b < nbatch (taps = 1, H = W = 1, plain rows), no split-K
+// out[b][cout_pad][cin_pad] = dy[b]^T x[b] for b < nbatch (taps = 1, H = W = 1, plain rows); split-K through
+// `scratch` only when the launch would under-fill the chip
 hipError_t launch_wgrad_batched(WgradArgs a, float* out, int nbatch, long long dy_bstride, long long x_bstride,
-                                hipStream_t stream);
+                                float* scratch, size_t scratch_floats, hipStream_t stream);
 
 // ---- BatchNorm (batch statistics) + PReLU, forward and backward (train_ops.hip) -------------------
 struct BnBuffers {       // per layer, [G][Cp] floats each unless noted

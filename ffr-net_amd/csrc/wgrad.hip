@@ -25,10 +25,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // BM x 128 output tile, BK = 32 rows per K-tile, 4 waves as 2 x 2
-template <int BM>
+// PLAIN: taps == 1 on plain rows (H = W = 1): the gather is a row pointer, no pixel arithmetic
+template <int BM, int BN, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
-    constexpr int BN = 128;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    // BN = 32: the input side of a Linear(32, .) -- four waves stacked along the output channels
+    constexpr int WARPS_N = BN == 32 ? 1 : 2, WARPS_M = 4 / WARPS_N;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N, TM = WM / 32, TN = WN / 32;
+    constexpr int SWZ = BN == 32 ? 0 : 1;         // rows of 32 floats alternate bank halves by themselves
     constexpr int A_INSTR = BM / 32;              // DMA instructions per wave and K-tile for the dy tile
     constexpr int B_INSTR = BN / 32;
     constexpr int STAGE = 32 * (BM + BN);
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WARPS_N, wn = wave % WARPS_N;
     const int par = lane >> 5;                    // k parity this lane stages and reads
 
     int bid = blockIdx.x;
@@ -53,9 +56,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 
     // this lane's 16-byte piece inside a staged row: position cpos, logical column chunk cl
     const int cposA = lane & (BM / 4 - 1);        // BM/4 pieces per row
-    const int cpos = lane & 31;
+    const int cpos = lane & (BN / 4 - 1);
     const int clA = cposA ^ (((lane / (BM / 4)) & 1) << 3);   // parity of the row this lane stages
-    const int cl = cpos ^ (par << 3);
+    const int cl = SWZ ? cpos ^ (par << 3) : cpos;
     // B column -> (tap, ci)
     const int j = n0 + cl * 4;
     const bool jok = j < a.Ng;
@@ -80,10 +83,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #pragma unroll
         for (int q = 0; q < B_INSTR; ++q) {
             const int piece = (q * 4 + wave) * 64;
-            const int k = (piece + lane) >> 5;
+            const int k = (piece + lane) / (BN / 4);
             const int m = m0 + k;
             const float* src = a.zero;
-            if (jok && m < a.rows) {
+            if (PLAIN) {
+                if (jok && m < a.rows) src = xb + (size_t)m * a.x_pitch + ci;
+            } else if (jok && m < a.rows) {
                 const int img = m / HW;
                 const int p = m - img * HW;
                 int h = p / a.W;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) colA[i] = (wm * WM + i * 32 + (lane & 31)) ^ (par << 5);
 #pragma unroll
-    for (int jj = 0; jj < TN; ++jj) colB[jj] = (wn * WN + jj * 32 + (lane & 31)) ^ (par << 5);
+    for (int jj = 0; jj < TN; ++jj) colB[jj] = (wn * WN + jj * 32 + (lane & 31)) ^ (SWZ ? (par << 5) : 0);
 
     if (kt0 < kt1) {
         stage_tile(0, kt0);
@@ -126,25 +131,32 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
             if (kt + 1 < kt1) stage_tile(cur ^ 1, kt + 1);
             const float* sA = smem + cur * STAGE;
             const float* sB = sA + 32 * BM;
+            // fragments of step kk + 1 are read before the MFMAs of step kk (register double buffer)
+            float av[2][TM], bv[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[0][i] = sA[par * BM + colA[i]];
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) bv[0][jj] = sB[par * BN + colB[jj]];
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const int k = kk * 2 + par;
-                float av[TM], bv[TN];
+                if (kk + 1 < 16) {
+                    const int k = (kk + 1) * 2 + par;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = sA[k * BM + colA[i]];
+                    for (int i = 0; i < TM; ++i) av[(kk + 1) & 1][i] = sA[k * BM + colA[i]];
 #pragma unroll
-                for (int jj = 0; jj < TN; ++jj) bv[jj] = sB[k * BN + colB[jj]];
+                    for (int jj = 0; jj < TN; ++jj) bv[(kk + 1) & 1][jj] = sB[k * BN + colB[jj]];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int jj = 0; jj < TN; ++jj)
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jj], acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][jj], acc[i][jj], 0, 0, 0);
             }
             cur ^= 1;
         }
     }
     // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* out = a.out + (size_t)split * a.cout_pad * a.Ng + (long long)batch * a.out_bstride;
+    float* out = a.out + (long long)split * a.split_stride + (long long)batch * a.out_bstride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -171,14 +183,27 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     reinterpret_cast<f32x4*>(grad)[i] = s;
 }
 
+template <int BM, int BN>
+static void wgrad_launch(const WgradArgs& a, unsigned grid, bool plain, hipStream_t stream) {
+    if (plain) hipLaunchKernelGGL((k_wgrad<BM, BN, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_wgrad<BM, BN, false>), dim3(grid), dim3(256), 0, stream, a);
+}
+
+static void wgrad_dispatch(const WgradArgs& a, int bm, int bn, unsigned grid, bool plain, hipStream_t stream) {
+    if (bn == 32) wgrad_launch<128, 32>(a, grid, plain, stream);
+    else if (bm == 128) wgrad_launch<128, 128>(a, grid, plain, stream);
+    else wgrad_launch<64, 128>(a, grid, plain, stream);
+}
+
 hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch, size_t scratch_floats,
                         hipStream_t stream) {
     if (a.cout_pad % 64 || a.cin_pad % 4 || (a.taps != 1 && a.taps != 9) || a.rows <= 0) return hipErrorInvalidValue;
     a.Ng = a.taps * a.cin_pad;
     if (a.Ng % 4) return hipErrorInvalidValue;
+    const int bn = (a.Ng == 32 && a.cout_pad % 128 == 0) ? 32 : 128;
     const int bm = (a.cout_pad % 128 == 0) ? 128 : 64;
     a.mtiles = a.cout_pad / bm;
-    a.ntiles = (a.Ng + 127) / 128;
+    a.ntiles = (a.Ng + bn - 1) / bn;
     a.nkt = (a.rows + 31) / 32;
     // enough blocks for two rounds over the chip, at least 8 K-tiles per split
     const long long tiles = (long long)a.mtiles * a.ntiles;
@@ -193,31 +218,48 @@ hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch
     a.splits = splits;
     a.out = scratch;
     a.nbatch = 1; a.dy_bstride = 0; a.x_bstride = 0; a.out_bstride = 0;
+    a.split_stride = (long long)per;
     const unsigned grid = (unsigned)(tiles * splits);
-    if (bm == 128) hipLaunchKernelGGL(k_wgrad<128>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_wgrad<64>, dim3(grid), dim3(256), 0, stream, a);
+    wgrad_dispatch(a, bm, bn, grid, a.taps == 1 && a.H == 1 && a.W == 1, stream);
     const long long n4 = (long long)per / 4;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, grad, n4, splits,
                        accumulate);
     return hipGetLastError();
 }
 
-// nbatch independent products out[b][cout_pad][cin_pad] = dy[b]^T x[b] (no split-K, no reduction pass):
-// the 36 Winograd-domain weight gradients dU[xi] = dM[xi]^T V[xi]
+// nbatch independent products out[b][cout_pad][cin_pad] = dy[b]^T x[b]: the 36 Winograd-domain weight gradients
+// dU[xi] = dM[xi]^T V[xi].  Launches that would leave the chip under-filled are cut along K into slabs
+// scratch[split][b][..] that k_wgrad_reduce adds in order; otherwise the result is written to `out` directly.
 hipError_t launch_wgrad_batched(WgradArgs a, float* out, int nbatch, long long dy_bstride, long long x_bstride,
-                                hipStream_t stream) {
-    if (a.cout_pad % 64 || a.cin_pad % 4 || a.taps != 1 || a.rows <= 0 || nbatch <= 0) return hipErrorInvalidValue;
+                                float* scratch, size_t scratch_floats, hipStream_t stream) {
+    if (a.cout_pad % 64 || a.cin_pad % 4 || a.taps != 1 || a.rows <= 0 || nbatch <= 0 || a.H != 1 || a.W != 1)
+        return hipErrorInvalidValue;
     a.Ng = a.cin_pad;
     const int bm = (a.cout_pad % 128 == 0) ? 128 : 64;
     a.mtiles = a.cout_pad / bm;
     a.ntiles = (a.Ng + 127) / 128;
     a.nkt = (a.rows + 31) / 32;
-    a.splits = 1; a.kt_per_split = a.nkt;
-    a.out = out;
+    const long long blocks = (long long)a.mtiles * a.ntiles * nbatch;
+    const size_t per = (size_t)a.cout_pad * a.Ng * nbatch;
+    int splits = 1;
+    if (blocks < 512) {
+        splits = (int)((768 + blocks - 1) / blocks);
+        if (splits > a.nkt / 4) splits = a.nkt / 4;
+        if (splits < 1) splits = 1;
+        while (splits > 1 && (size_t)splits * per > scratch_floats) --splits;
+    }
+    a.kt_per_split = (a.nkt + splits - 1) / splits;
+    splits = (a.nkt + a.kt_per_split - 1) / a.kt_per_split;
+    a.splits = splits;
+    a.out = splits > 1 ? scratch : out;
     a.nbatch = nbatch; a.dy_bstride = dy_bstride; a.x_bstride = x_bstride; a.out_bstride = (long long)a.cout_pad * a.Ng;
-    const unsigned grid = (unsigned)((long long)a.mtiles * a.ntiles * nbatch);
-    if (bm == 128) hipLaunchKernelGGL(k_wgrad<128>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_wgrad<64>, dim3(grid), dim3(256), 0, stream, a);
+    a.split_stride = (long long)per;
+    const unsigned grid = (unsigned)(blocks * splits);
+    wgrad_dispatch(a, bm, 128, grid, true, stream);
+    if (splits > 1) {
+        const long long n4 = (long long)per / 4;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, out, n4, splits, 0);
+    }
     return hipGetLastError();
 }
 
