@@ -522,15 +522,15 @@ hipError_t launch_prelu_rows(const float* x, float* out, int pitch, int C, const
     return hipGetLastError();
 }
 
-// one thread per row (C <= 64 columns): in-place gradient + the row's contribution to dslope
+// 16 lanes per row of 64 columns (one float4 each): in-place gradient + the row's contribution to dslope
 __global__ __launch_bounds__(256) void k_prelu_rows_bwd(float* __restrict__ dy, const float* __restrict__ x, int pitch,
                                                        int C, const float* __restrict__ slope, long long rows,
                                                        float* __restrict__ rowdot) {
-    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
-    const float sl = slope[row & 511];
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = (threadIdx.x & 15) * 4;
     float acc = 0.f;
-    for (int c = 0; c < C; c += 4) {
+    if (row < rows && c < C) {
+        const float sl = slope[row & 511];
         f32x4 d = *reinterpret_cast<f32x4*>(dy + row * pitch + c);
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * pitch + c);
 #pragma unroll
@@ -539,25 +539,34 @@ __global__ __launch_bounds__(256) void k_prelu_rows_bwd(float* __restrict__ dy, 
         }
         *reinterpret_cast<f32x4*>(dy + row * pitch + c) = d;
     }
-    rowdot[row] = acc;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (row < rows && (threadIdx.x & 15) == 0) rowdot[row] = acc;
 }
 
+// dslope[c] (+)= sum over the images of rowdot[n*512 + c]; 64 channels x 4 image lanes per block
 __global__ __launch_bounds__(256) void k_rowdot_to_slope(const float* __restrict__ rowdot, long long imgs, float* dslope,
                                                         int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 512) return;
+    __shared__ double sh[4][64];
+    const int t = threadIdx.x & 63, il = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + t;
     double a = 0.0;
-    for (long long n = 0; n < imgs; ++n) a += (double)rowdot[n * 512 + c];
-    if (accumulate) a += dslope[c];
-    dslope[c] = (float)a;
+    for (long long n = il; n < imgs; n += 4) a += (double)rowdot[n * 512 + c];
+    sh[il][t] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        a = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+        if (accumulate) a += dslope[c];
+        dslope[c] = (float)a;
+    }
 }
 
 hipError_t launch_prelu_rows_bwd(float* dy, const float* x, int pitch, int C, const float* slope, long long rows,
                                  float* rowdot, float* dslope, int accumulate, hipStream_t stream) {
-    if ((pitch | C) & 3 || rows % 512) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_prelu_rows_bwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, dy, x, pitch, C, slope,
+    if ((pitch | C) & 3 || rows % 512 || C > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_prelu_rows_bwd, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, dy, x, pitch, C, slope,
                        rows, rowdot);
-    hipLaunchKernelGGL(k_rowdot_to_slope, dim3(2), dim3(256), 0, stream, rowdot, rows / 512, dslope, accumulate);
+    hipLaunchKernelGGL(k_rowdot_to_slope, dim3(8), dim3(256), 0, stream, rowdot, rows / 512, dslope, accumulate);
     return hipGetLastError();
 }
 
@@ -608,28 +617,35 @@ hipError_t launch_cat_to_draw(const float* dF, float* draw, int imgs, hipStream_
     return hipGetLastError();
 }
 
-// block per image; thread per (j, i) pair in turn; both rows are contiguous 512-vectors
+// block per (image, j): the gradient row dFS[j] in LDS, one wave-quarter (16 lanes) per i, 512-long dot products
 __global__ __launch_bounds__(256) void k_space_apply_bwd(const float* __restrict__ dFS, int d_pitch, int d_coff,
                                                         const float* __restrict__ X, float* __restrict__ dms) {
-    const int n = blockIdx.x;
-    for (int o = threadIdx.x; o < 49 * 64; o += 256) {
-        const int j = o >> 6, i = o & 63;
+    __shared__ __attribute__((aligned(16))) float g[512];
+    const int n = blockIdx.y, j = blockIdx.x;
+    for (int c = threadIdx.x; c < 512; c += 256) g[c] = dFS[((size_t)n * 49 + j) * d_pitch + d_coff + c];
+    __syncthreads();
+    const int grp = threadIdx.x >> 4, l = threadIdx.x & 15;       // 16 groups of 16 lanes
+    for (int i = grp; i < 64; i += 16) {
         float acc = 0.f;
         if (i < 49) {
-            const f32x4* a = reinterpret_cast<const f32x4*>(dFS + ((size_t)n * 49 + j) * d_pitch + d_coff);
-            const f32x4* b = reinterpret_cast<const f32x4*>(X + ((size_t)n * 49 + i) * 512);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < 128; ++c) s += a[c] * b[c];
-            acc = (s[0] + s[1]) + (s[2] + s[3]);
+            const float* xr = X + ((size_t)n * 49 + i) * 512;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(g + (q * 16 + l) * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(xr + (q * 16 + l) * 4);
+                acc += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+            }
         }
-        dms[((size_t)n * 49 + j) * 64 + i] = acc;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (l == 0) dms[((size_t)n * 49 + j) * 64 + i] = acc;
     }
 }
 
 hipError_t launch_space_apply_bwd(const float* dFS, int d_pitch, int d_coff, const float* X, float* dms, int imgs,
                                   hipStream_t stream) {
     if ((d_pitch | d_coff) & 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_space_apply_bwd, dim3(imgs), dim3(256), 0, stream, dFS, d_pitch, d_coff, X, dms);
+    hipLaunchKernelGGL(k_space_apply_bwd, dim3(49, imgs), dim3(256), 0, stream, dFS, d_pitch, d_coff, X, dms);
     return hipGetLastError();
 }
 
@@ -1160,28 +1176,35 @@ hipError_t launch_ce_loss(const float* cosv, int cos_pitch, const int* label, in
     return hipGetLastError();
 }
 
-// single block; every sum in index order
-__global__ __launch_bounds__(64) void k_loss_finish(LossParts p, int N, LossCoef c, float* out) {
-    if (threadIdx.x != 0) return;
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < 2 * N; ++i) a += p.ss_space[i];
-    for (int i = 0; i < p.n_ssc; ++i) b += p.ss_channel[i];
-    out[0] = (float)(a * (double)c.w_ss_space + b * (double)c.w_ss_channel);
-    double t = 0.0, id = 0.0;
-    for (int i = 0; i < 2 * N; ++i) id += p.vec[i];
-    for (int i = N; i < 2 * N; ++i) t += p.vec[2 * N + i];
-    out[1] = (float)(t * (double)c.w_triplet);
-    out[2] = (float)(id * (double)c.w_identity);
-    double cn = 0.0, co = 0.0;
-    int hits = 0;
-    for (int i = 0; i < N; ++i) cn += p.ce[i];
-    for (int i = N; i < 2 * N; ++i) { co += p.ce[i]; hits += p.hit[i]; }
-    out[3] = (float)(cn * (double)c.w_ce_non + co * (double)c.w_ce_ocl);
-    out[4] = (float)hits / (float)N;
+// single block of 256 threads; every sum has a fixed order (thread t adds elements t, t+256, ... then a fixed tree)
+__device__ __forceinline__ double block_sum_strided(const double* __restrict__ p, int lo, int hi, double* sh) {
+    double a = 0.0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) a += p[i];
+    return block_sum_double(a, sh);
+}
+
+__global__ __launch_bounds__(256) void k_loss_finish(LossParts p, int N, LossCoef c, float* out) {
+    __shared__ double sh[4];
+    const double a = block_sum_strided(p.ss_space, 0, 2 * N, sh);
+    const double b = block_sum_strided(p.ss_channel, 0, p.n_ssc, sh);
+    const double id = block_sum_strided(p.vec, 0, 2 * N, sh);
+    const double t = block_sum_strided(p.vec, 3 * N, 4 * N, sh);
+    const double cn = block_sum_strided(p.ce, 0, N, sh);
+    const double co = block_sum_strided(p.ce, N, 2 * N, sh);
+    double hits = 0.0;
+    for (int i = N + (int)threadIdx.x; i < 2 * N; i += 256) hits += (double)p.hit[i];
+    hits = block_sum_double(hits, sh);
+    if (threadIdx.x == 0) {
+        out[0] = (float)(a * (double)c.w_ss_space + b * (double)c.w_ss_channel);
+        out[1] = (float)(t * (double)c.w_triplet);
+        out[2] = (float)(id * (double)c.w_identity);
+        out[3] = (float)(cn * (double)c.w_ce_non + co * (double)c.w_ce_ocl);
+        out[4] = (float)(hits / (double)N);
+    }
 }
 
 hipError_t launch_loss_finish(LossParts p, int N, LossCoef c, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(64), 0, stream, p, N, c, out);
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, stream, p, N, c, out);
     return hipGetLastError();
 }
 
