@@ -44,35 +44,49 @@ __global__ __launch_bounds__(256) void k_bn_stats_partial(const float* __restric
     }
 }
 
-// one thread per channel; groups in order (the running statistics see them one after the other)
-__global__ __launch_bounds__(64) void k_bn_stats_final(const double* __restrict__ part, int Cp, int G, int nsl, int rows_g,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float* running_mean, float* running_var, float momentum,
-                                                      float eps, BnBuffers b) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= Cp) return;
-    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+// 64 channels x 4 slice lanes per block; groups in order (the running statistics see them one after the other)
+__global__ __launch_bounds__(256) void k_bn_stats_final(const double* __restrict__ part, int Cp, int G, int nsl, int rows_g,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* running_mean, float* running_var, float momentum,
+                                                       float eps, BnBuffers b) {
+    __shared__ double sh[2][4][64];
+    const int t = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + t;
+    float rm = 0.f, rv = 0.f;
+    if (threadIdx.x < 64) {
+        rm = running_mean ? running_mean[c] : 0.f;
+        rv = running_var ? running_var[c] : 0.f;
+    }
     for (int g = 0; g < G; ++g) {
         double s1 = 0.0, s2 = 0.0;
-        for (int s = 0; s < nsl; ++s) {
+        for (int s = sl; s < nsl; s += 4) {
             const double* p = part + ((size_t)(g * nsl + s) * 3) * Cp + c;
             s1 += p[0]; s2 += p[Cp];
         }
-        const double mean = s1 / rows_g;
-        double var = s2 / rows_g - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        b.mean[g * Cp + c] = (float)mean;
-        b.invstd[g * Cp + c] = invstd;
-        b.scale[g * Cp + c] = sc;
-        b.shift[g * Cp + c] = beta[c] - (float)mean * sc;
-        const float unbiased = (float)(var * ((double)rows_g / (double)(rows_g > 1 ? rows_g - 1 : 1)));
-        rm = (1.f - momentum) * rm + momentum * (float)mean;
-        rv = (1.f - momentum) * rv + momentum * unbiased;
+        __syncthreads();
+        sh[0][sl][t] = s1; sh[1][sl][t] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            s1 = (sh[0][0][t] + sh[0][1][t]) + (sh[0][2][t] + sh[0][3][t]);
+            s2 = (sh[1][0][t] + sh[1][1][t]) + (sh[1][2][t] + sh[1][3][t]);
+            const double mean = s1 / rows_g;
+            double var = s2 / rows_g - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            b.mean[g * Cp + c] = (float)mean;
+            b.invstd[g * Cp + c] = invstd;
+            b.scale[g * Cp + c] = sc;
+            b.shift[g * Cp + c] = beta[c] - (float)mean * sc;
+            const float unbiased = (float)(var * ((double)rows_g / (double)(rows_g > 1 ? rows_g - 1 : 1)));
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
     }
-    if (running_mean) running_mean[c] = rm;
-    if (running_var) running_var[c] = rv;
+    if (threadIdx.x < 64) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+    }
 }
 
 hipError_t launch_bn_stats(const float* y, int Cp, int G, int rows_g, const float* gamma, const float* beta,
@@ -81,7 +95,7 @@ hipError_t launch_bn_stats(const float* y, int Cp, int G, int rows_g, const floa
     if (Cp % 64 || G <= 0 || rows_g <= 0) return hipErrorInvalidValue;
     const int nsl = n_slices(rows_g);
     hipLaunchKernelGGL(k_bn_stats_partial, dim3(Cp / 64, nsl, G), dim3(256), 0, stream, y, Cp, rows_g, slice_rows(rows_g), part);
-    hipLaunchKernelGGL(k_bn_stats_final, dim3(Cp / 64), dim3(64), 0, stream, part, Cp, G, nsl, rows_g, gamma, beta,
+    hipLaunchKernelGGL(k_bn_stats_final, dim3(Cp / 64), dim3(256), 0, stream, part, Cp, G, nsl, rows_g, gamma, beta,
                        running_mean, running_var, momentum, eps, b);
     return hipGetLastError();
 }
@@ -159,23 +173,34 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void k_bn_bwd_final(const double* __restrict__ part, int Cp, int G, int nsl, int rows_g,
-                                                    BnBuffers b, float* dgamma, float* dbeta, float* dslope, int accumulate) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= Cp) return;
+__global__ __launch_bounds__(256) void k_bn_bwd_final(const double* __restrict__ part, int Cp, int G, int nsl, int rows_g,
+                                                     BnBuffers b, float* dgamma, float* dbeta, float* dslope, int accumulate) {
+    __shared__ double sh[3][4][64];
+    const int t = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + t;
     double tg = 0.0, tb = 0.0, ts = 0.0;
     for (int g = 0; g < G; ++g) {
         double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        for (int s = 0; s < nsl; ++s) {
+        for (int s = sl; s < nsl; s += 4) {
             const double* p = part + ((size_t)(g * nsl + s) * 3) * Cp + c;
             s1 += p[0]; s2 += p[Cp]; s3 += p[2 * (size_t)Cp];
         }
-        b.c1[g * Cp + c] = (float)(s1 / rows_g);
-        b.c2[g * Cp + c] = (float)(s2 / rows_g);
-        tb += s1; tg += s2; ts += s3;
+        __syncthreads();
+        sh[0][sl][t] = s1; sh[1][sl][t] = s2; sh[2][sl][t] = s3;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            s1 = (sh[0][0][t] + sh[0][1][t]) + (sh[0][2][t] + sh[0][3][t]);
+            s2 = (sh[1][0][t] + sh[1][1][t]) + (sh[1][2][t] + sh[1][3][t]);
+            s3 = (sh[2][0][t] + sh[2][1][t]) + (sh[2][2][t] + sh[2][3][t]);
+            b.c1[g * Cp + c] = (float)(s1 / rows_g);
+            b.c2[g * Cp + c] = (float)(s2 / rows_g);
+            tb += s1; tg += s2; ts += s3;
+        }
     }
-    if (accumulate) { tg += dgamma[c]; tb += dbeta[c]; ts += dslope[c]; }
-    dgamma[c] = (float)tg; dbeta[c] = (float)tb; dslope[c] = (float)ts;
+    if (threadIdx.x < 64) {
+        if (accumulate) { tg += dgamma[c]; tb += dbeta[c]; ts += dslope[c]; }
+        dgamma[c] = (float)tg; dbeta[c] = (float)tb; dslope[c] = (float)ts;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ da, int da_pitch, int da_coff,
@@ -214,7 +239,7 @@ hipError_t launch_bn_bwd(const float* da, int da_pitch, int da_coff, const float
     const int nsl = n_slices(rows_g);
     hipLaunchKernelGGL(k_bn_bwd_partial, dim3(Cp / 64, nsl, G), dim3(256), 0, stream, da, da_pitch, da_coff, y, Cp, rows_g,
                        slice_rows(rows_g), b, slope, part);
-    hipLaunchKernelGGL(k_bn_bwd_final, dim3(Cp / 64), dim3(64), 0, stream, part, Cp, G, nsl, rows_g, b, dgamma, dbeta,
+    hipLaunchKernelGGL(k_bn_bwd_final, dim3(Cp / 64), dim3(256), 0, stream, part, Cp, G, nsl, rows_g, b, dgamma, dbeta,
                        dslope, accumulate);
     const long long total4 = (long long)G * rows_g * (Cp >> 2);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, da, da_pitch, da_coff, y,
@@ -439,8 +464,8 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double* __restrict__
 hipError_t launch_colsum(const float* x, int pitch, int rows, int Cp, float* out, int accumulate, double* part,
                          hipStream_t stream) {
     if (Cp % 64) return hipErrorInvalidValue;
-    int nsl = (rows + 97) / 98;            // up to 512 slices: tall, narrow inputs (131072 x 64) need the blocks
-    if (nsl > 512) nsl = 512;
+    int nsl = (rows + 97) / 98;            // up to 128 slices: tall, narrow inputs (131072 x 64) need the blocks
+    if (nsl > 128) nsl = 128;
     const int sr = (rows + nsl - 1) / nsl;
     hipLaunchKernelGGL(k_colsum_partial, dim3(Cp / 64, nsl), dim3(256), 0, stream, x, pitch, rows, Cp, sr, part);
     hipLaunchKernelGGL(k_colsum_final, dim3(Cp / 64), dim3(256), 0, stream, part, Cp, nsl, out, accumulate);

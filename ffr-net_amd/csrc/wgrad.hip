@@ -172,15 +172,22 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
         }
 }
 
-// grad[i] (+)= scale * sum_s slabs[s][i]
+// grad[i] (+)= sum_s slabs[s][i]: 64 float4 outputs x 4 split lanes per block, fixed combination order
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ grad,
                                                      long long n4, int splits, int accumulate) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    f32x4 s = reinterpret_cast<const f32x4*>(slabs)[i];
-    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
-    if (accumulate) s += reinterpret_cast<const f32x4*>(grad)[i];
-    reinterpret_cast<f32x4*>(grad)[i] = s;
+    __shared__ f32x4 sh[4][64];
+    const int t = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + t;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int k = sl; k < splits; k += 4) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
+    sh[sl][t] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && i < n4) {
+        s = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+        if (accumulate) s += reinterpret_cast<const f32x4*>(grad)[i];
+        reinterpret_cast<f32x4*>(grad)[i] = s;
+    }
 }
 
 template <int BM, int BN>
@@ -222,7 +229,7 @@ hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch
     const unsigned grid = (unsigned)(tiles * splits);
     wgrad_dispatch(a, bm, bn, grid, a.taps == 1 && a.H == 1 && a.W == 1, stream);
     const long long n4 = (long long)per / 4;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, grad, n4, splits,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, scratch, grad, n4, splits,
                        accumulate);
     return hipGetLastError();
 }
@@ -258,7 +265,7 @@ hipError_t launch_wgrad_batched(WgradArgs a, float* out, int nbatch, long long d
     wgrad_dispatch(a, bm, 128, grid, true, stream);
     if (splits > 1) {
         const long long n4 = (long long)per / 4;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, scratch, out, n4, splits, 0);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, scratch, out, n4, splits, 0);
     }
     return hipGetLastError();
 }
