@@ -464,8 +464,8 @@ __global__ __launch_bounds__(256) void k_colsum_final(const double* __restrict__
 hipError_t launch_colsum(const float* x, int pitch, int rows, int Cp, float* out, int accumulate, double* part,
                          hipStream_t stream) {
     if (Cp % 64) return hipErrorInvalidValue;
-    int nsl = (rows + 97) / 98;            // up to 128 slices: tall, narrow inputs (131072 x 64) need the blocks
-    if (nsl > 128) nsl = 128;
+    int nsl = (rows + 97) / 98;            // up to 384 slices: tall, narrow inputs (131072 x 64) need the blocks
+    if (nsl > 384) nsl = 384;
     const int sr = (rows + nsl - 1) / nsl;
     hipLaunchKernelGGL(k_colsum_partial, dim3(Cp / 64, nsl), dim3(256), 0, stream, x, pitch, rows, Cp, sr, part);
     hipLaunchKernelGGL(k_colsum_final, dim3(Cp / 64), dim3(256), 0, stream, part, Cp, nsl, out, accumulate);
