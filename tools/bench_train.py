@@ -15,6 +15,7 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--cpu-baseline', action='store_true', help='also time the oracle (torch CPU autograd) on a small batch')
     a = ap.parse_args()
     specs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g0_state_dict_keys.json')))
     eng = ffrnet_amd.Engine(0)
@@ -58,7 +59,31 @@ def main():
         items = tr.step(non, ocl, label)
     torch.cuda.synchronize()
     step_ms = (time.perf_counter() - t0) / a.steps * 1e3
-    print(json.dumps({'metric': 'RecNet training iterations/s (encoder frozen; clean+occluded pairs)', 'batch_pairs_per_gpu': n,
+    # algorithmic work (SURVEY 8d counting: direct convolutions, 2*MACs): encoder 12.5934 GFLOP/image forward only,
+    # RecNet 2.5493 GFLOP/image forward and twice that backward (data + weight gradients)
+    gflop = 2 * n * (12.5934 + 3 * 2.5493)
+    roof = {'bound': 'mfma', 'achieved': round(gflop / step_ms, 2), 'peak': 157.3, 'unit': 'TFLOP/s',
+            'frac': round(gflop / step_ms / 157.3, 4), 'gflop_per_iteration': round(gflop, 1),
+            'note': 'algorithmic direct-convolution FLOPs per iteration / wall time; Winograd executes fewer multiplies'}
+    cpu = None
+    if a.cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import ffr_oracle_train as OT
+        nb = 8
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+        sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+        cn, co, cl = synth.synth_train_batch(nb, seed=11)
+        opt = OT.new_adam_state(sd_r)
+        OT.train_step(sd_e, sd_r, opt, cn, co, cl, lr=1e-3)
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            OT.train_step(sd_e, sd_r, opt, cn, co, cl, lr=1e-3)
+        dt = (time.perf_counter() - t0) / reps
+        cpu = {'value': round(nb / dt, 2), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '%d pairs per iteration, %d iterations, torch %s CPU autograd (oracle/ffr_oracle_train.py)' % (nb, reps, torch.__version__)}
+    print(json.dumps({'roofline': roof, 'cpu_baseline': cpu, 'metric': 'RecNet training iterations/s (encoder frozen; clean+occluded pairs)', 'batch_pairs_per_gpu': n,
                       'ms_per_step': round(step_ms, 3), 'pairs_per_s': round(n / step_ms * 1e3, 1), 'phase_ms': ms,
                       'phased_ms_per_step': round(wall / a.steps * 1e3, 3), 'losses': [round(float(l), 5) for l in items]}))
 
