@@ -199,6 +199,15 @@ hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, c
     return hipGetLastError();
 }
 
+// the second half alone: `part` [N][S][C] was already written by the producer of `res` (k_wino_out, one partial
+// sum per 4x4 output tile)
+hipError_t launch_se_fc(const float* part, int N, int S, int HW, int C, const float* fc1, const float* fc2, float* scale,
+                        hipStream_t stream) {
+    if (C > 512 || (C & 63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_se_fc, dim3(N), dim3(256), 0, stream, part, S, HW, C, fc1, fc2, scale);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // out = res * se_scale + shortcut    (bottleneck_IR_SE.forward, model_ir_se50.py:73-76;
 // MaxPool2d(1, stride) shortcut = strided subsample, :60)

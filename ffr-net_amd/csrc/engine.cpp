@@ -352,8 +352,11 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 RC(run_gemm(h, g, c, flops / nslice, bytes / nslice, st));
                 }
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * Ts * L.cout_pad + (double)M / nslice * L.cout));
+                const bool sums = c.tile_sums && nslice == 1;
                 HIPCK(h, launch_wino_out(c.winoM, L.bias, L.slope, rs, c.res_pitch, os, c.out_pitch, c.out_coff,
-                                         c.cout_store, L.cout_pad, Ns, c.H, c.W, L.border, c.flags, st));
+                                         c.cout_store, L.cout_pad, Ns, c.H, c.W, L.border, c.flags, st,
+                                         sums ? c.tile_sums : nullptr));
+                if (sums && c.tile_sums_written) *c.tile_sums_written = true;
             }
             return FFR_OK;
         }
@@ -458,11 +461,20 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         c2.x = w.t1; c2.N = N; c2.H = ch; c2.W = cw; c2.in_pitch = b.depth;
         c2.out = w.res; c2.out_pitch = b.depth; c2.cout_store = b.depth;
         c2.partial = w.partial; c2.partial_cap = w.partial_cap; c2.tickets = w.tickets; c2.tickets_cap = w.tickets_cap; c2.winoV = w.winoV; c2.winoM = w.winoM; c2.wino_cap = w.wino_cap;
+        // SE squeeze: the Winograd output transform of conv2 leaves one partial sum per 4x4 tile in se_part
+        // ([N][tiles][C], the layout k_se_fc reads); the direct path (stride 2, 64 channels) pools separately
+        bool pooled = false;
+        const int tiles = ((ho + 3) / 4) * ((wo + 3) / 4);
+        static const bool se_fuse = !(getenv("FFR_SE_FUSE") && atoi(getenv("FFR_SE_FUSE")) == 0);
+        if (se_fuse && b.stride == 1 && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
+            c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
+        }
         RC(run_conv(h, b.c2, c2, st));
         {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_SE, e + 4.0 * N * b.depth * (b.depth / 16), 4.0 * e);
-            HIPCK(h, launch_se(w.res, N, ho * wo, b.depth, b.fc1, b.fc2, w.scale, w.se_part, st));
+            if (pooled) HIPCK(h, launch_se_fc(w.se_part, N, tiles, ho * wo, b.depth, b.fc1, b.fc2, w.scale, st));
+            else HIPCK(h, launch_se(w.res, N, ho * wo, b.depth, b.fc1, b.fc2, w.scale, w.se_part, st));
         }
         const float* scp = nullptr;
         if (b.has_sc) {

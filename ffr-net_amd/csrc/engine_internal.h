@@ -147,6 +147,8 @@ struct ConvCall {
     int* tickets; size_t tickets_cap;
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
     int wino_mode = -1;                            // -1 auto (env FFR_WINO), 0 never, 1 whenever packed
+    float* tile_sums = nullptr;                    // Winograd path only: per-tile sums of the stored outputs [T][cout_pad]
+    bool* tile_sums_written = nullptr;             // set to true when the Winograd path wrote them
 };
 
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st);

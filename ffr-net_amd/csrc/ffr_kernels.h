@@ -60,7 +60,8 @@ hipError_t launch_wino_dweights(const float* dU, float* grad, int out_pad, int i
 // out = epilogue(A^T M A): bias[(border class)][cout_pad], PReLU, residual, sigmoid (flags bit0)
 hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
                            float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,
-                           int border_bias, int flags, hipStream_t stream);
+                           int border_bias, int flags, hipStream_t stream, float* tile_sums = nullptr);
+// tile_sums [T][cout_pad] (optional): the sum of every tile's stored outputs -- the SE squeeze partials
 
 // ---- trunk elementwise (elementwise.hip) -------------------------------------------
 // stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded
@@ -74,6 +75,8 @@ hipError_t launch_stem(const float* x_nchw, const unsigned char* xu8, const unsi
 int se_slices(int N, int HW);
 hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, const float* fc2,
                      float* scale, float* part, hipStream_t stream);
+hipError_t launch_se_fc(const float* part, int N, int S, int HW, int C, const float* fc1, const float* fc2, float* scale,
+                        hipStream_t stream);
 // out[n,ho,wo,c] = res*scale[n,c] + (sc ? sc[n,ho,wo,c] : x[n,ho*stride,wo*stride,c])
 hipError_t launch_combine(const float* res, const float* scale, const float* sc, const float* x,
                           float* out, int N, int Ho, int Wo, int C, int stride, hipStream_t stream);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
 }
 
 struct WinoOutArgs {
-    const float* M; const float* bias; const float* slope; const float* resid; float* out;
+    const float* M; const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
     int N, H, W, cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags, th, tw;
     long long T;
 };
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
     const bool vec = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0 && c4 + 4 <= a.cout_store;
     f32x4 slope4 = {1.f, 1.f, 1.f, 1.f};
     if (a.slope) slope4 = *reinterpret_cast<const f32x4*>(a.slope + c4);
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f32x4 y[4];
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
                     for (int e = 0; e < 4; ++e) v[e] = 1.0f / (1.0f + __expf(-v[e]));
                 }
                 *reinterpret_cast<f32x4*>(a.out + m * a.out_pitch + a.out_coff + c4) = v;
+                psum += v;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
             }
         }
     }
+    if (a.tile_sums) *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)t * a.cout_pad + c4) = psum;
 }
 
 // U[xi][o][i] = (G g G^T)[xi] of the 3x3 filter g = W[o][0..8][i]  (W [out_pad][9][in_pad], tap = r*3+s).
@@ -306,8 +309,9 @@ hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pit
 
 hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
                            float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,
-                           int border_bias, int flags, hipStream_t stream) {
+                           int border_bias, int flags, hipStream_t stream, float* tile_sums) {
     WinoOutArgs a;
+    a.tile_sums = tile_sums;
     a.M = M; a.bias = bias; a.slope = slope; a.resid = resid; a.out = out;
     a.N = N; a.H = H; a.W = W; a.cout_pad = cout_pad; a.cout_store = cout_store; a.out_pitch = out_pitch;
     a.out_coff = out_coff; a.res_pitch = res_pitch; a.border_bias = border_bias; a.flags = flags;
