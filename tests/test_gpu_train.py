@@ -449,3 +449,30 @@ def test_train_forward_small_and_odd_batches(engine, specs, n):
     for k, v in running.items():
         if k.endswith(('running_mean', 'running_var')):
             assert rel(sd_after[k], v) < 2e-4, k
+
+
+def test_trained_weights_feed_the_eval_path(specs):
+    """After training iterations the exported state_dict (torch layouts, running statistics) must drive the
+    verification path like any checkpoint: oracle eval forward == native eval forward on it, and the RecNet
+    embedding differs from the one before training."""
+    import ffr_oracle as O
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    non, ocl, label = synth.synth_train_batch(8, seed=91)
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    eng.load_recnet(sd_r)
+    x = synth.synth_images(4, seed=92)
+    f_before, _ = eng.embed(x.cuda())
+    tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
+    for _ in range(3):
+        tr.step(non.cuda(), ocl.cuda(), label.cuda())
+    sd_t = tr.state_dict()
+    assert set(sd_t) == set(sd_r) and all(sd_t[k].shape == sd_r[k].shape for k in sd_r)
+    assert int(sd_t['Conv4Space.0.norm.norm.num_batches_tracked']) == 6
+    eng.load_recnet(sd_t)
+    f_after, _ = eng.embed(x.cuda())
+    with torch.no_grad():
+        ref, _ = O.embed(sd_e, sd_t, x)
+    assert rel(f_after, ref) < 1e-3
+    assert rel(f_after, f_before.cpu()) > 1e-3
