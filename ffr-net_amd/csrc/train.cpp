@@ -38,6 +38,7 @@ struct TScratch {
     float* U = nullptr; size_t U_floats = 0;         // Winograd weights of the layer at hand (re-derived per use)
     float* canvas = nullptr; size_t canvas_floats = 0;   // dy embedded in a 9x9 zero-bordered map
     bool wino = !(getenv("FFR_TRAIN_WINO") && atoi(getenv("FFR_TRAIN_WINO")) == 0);   // ffr_train_option("winograd")
+    bool fold = true;                              // ffr_train_option("fold_channel")
 };
 
 void conv_call_common(ConvCall& c, const Work& w, bool wino = false) {
@@ -231,7 +232,7 @@ struct Ctx {
     float *Xt, *Xht, *cat, *h1pre, *h1, *t2, *h2pre, *h2, *t5, *h3pre, *h3, *Mc, *raw;
     float *fnew, *fn, *fnorm, *cosv, *wn, *wnorm;
     int* label;
-    bool valid = false;
+    bool valid = false, folded = false;
 };
 
 }  // namespace
@@ -258,6 +259,7 @@ struct TrainState {
     float *dRawt, *dMc, *dt, *d32a, *d32b, *rowdot, *dcos, *dfn, *df, *dwn, *wnT, *wT;
     // native loss items (ffr_train_losses)
     float *lYht, *lYh, *df_ext, *loss_out;
+    float *foldA[2], *foldd[2], *gfoldA, *gfoldd;     // Conv4Channel pairs folded to 32x32 (+ their gradients)
     double *p_sss, *p_ssc, *p_vec, *p_ce;
     int* hit;
     bool loss_grads_ready = false;
@@ -354,6 +356,8 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->d32a = a.take(crow * 64); t->d32b = a.take(crow * 64); t->rowdot = a.take(crow);
         t->dcos = a.take(imgs * CLS_PAD); t->dfn = a.take(imgs * 512); t->df = a.take(imgs * 512);
         t->dwn = a.take((size_t)CLS_PAD * 512); t->wnT = a.take((size_t)512 * CLS_PAD); t->wT = a.take((size_t)512 * 576);
+        for (int q = 0; q < 2; ++q) { t->foldA[q] = a.take(64 * 32); t->foldd[q] = a.take(64); }
+        t->gfoldA = a.take(64 * 32); t->gfoldd = a.take(64);
         t->lYht = a.take(crow * 64); t->lYh = a.take(imgs * 64 * 512); t->df_ext = a.take(imgs * 512); t->loss_out = a.take(64);
         t->p_sss = (double*)a.take(imgs * 2 + 64); t->p_ssc = (double*)a.take(imgs * 64 * 2 + 64);
         t->p_vec = (double*)a.take(imgs * 4 + 64); t->p_ce = (double*)a.take(imgs * 2 + 64); t->hit = (int*)a.take(imgs + 64);
@@ -405,11 +409,23 @@ int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream
     const Lin* ln = t->lin;
     RC(gemm_rows(h, w, c.cat, 576, 576, ln[0].w, ln[0].b, 64, c.h1pre, 64, crow, nullptr, 0, 0, st));
     HIPCK(h, launch_prelu_rows(c.h1pre, c.h1, 64, 64, t->a[0], crow, st));
-    RC(gemm_rows(h, w, c.h1, 64, 32, ln[1].w, ln[1].b, 512, c.t2, 512, crow, nullptr, 0, 0, st));
-    RC(gemm_rows(h, w, c.t2, 512, 512, ln[2].w, ln[2].b, 64, c.h2pre, 64, crow, nullptr, 0, 0, st));
+    c.folded = t->sc.fold;
+    if (c.folded) {
+        // Linear(32,512) -> Linear(512,32) pairs as their 32x32 product (exact algebra, as the inference kernel does)
+        HIPCK(h, launch_ch_fold(ln[2].w, ln[2].b, ln[1].w, ln[1].b, t->foldA[0], t->foldd[0], st));
+        HIPCK(h, launch_ch_fold(ln[4].w, ln[4].b, ln[3].w, ln[3].b, t->foldA[1], t->foldd[1], st));
+        RC(gemm_rows(h, w, c.h1, 64, 32, t->foldA[0], t->foldd[0], 64, c.h2pre, 64, crow, nullptr, 0, 0, st));
+    } else {
+        RC(gemm_rows(h, w, c.h1, 64, 32, ln[1].w, ln[1].b, 512, c.t2, 512, crow, nullptr, 0, 0, st));
+        RC(gemm_rows(h, w, c.t2, 512, 512, ln[2].w, ln[2].b, 64, c.h2pre, 64, crow, nullptr, 0, 0, st));
+    }
     HIPCK(h, launch_prelu_rows(c.h2pre, c.h2, 64, 64, t->a[1], crow, st));
-    RC(gemm_rows(h, w, c.h2, 64, 32, ln[3].w, ln[3].b, 512, c.t5, 512, crow, nullptr, 0, 0, st));
-    RC(gemm_rows(h, w, c.t5, 512, 512, ln[4].w, ln[4].b, 64, c.h3pre, 64, crow, nullptr, 0, 0, st));
+    if (c.folded) {
+        RC(gemm_rows(h, w, c.h2, 64, 32, t->foldA[1], t->foldd[1], 64, c.h3pre, 64, crow, nullptr, 0, 0, st));
+    } else {
+        RC(gemm_rows(h, w, c.h2, 64, 32, ln[3].w, ln[3].b, 512, c.t5, 512, crow, nullptr, 0, 0, st));
+        RC(gemm_rows(h, w, c.t5, 512, 512, ln[4].w, ln[4].b, 64, c.h3pre, 64, crow, nullptr, 0, 0, st));
+    }
     HIPCK(h, launch_prelu_rows(c.h3pre, c.h3, 64, 64, t->a[2], crow, st));
     RC(gemm_rows(h, w, c.h3, 64, 32, ln[5].w, ln[5].b, 512, c.Mc, 512, crow, nullptr, 0, 1 /*sigmoid*/, st));
     // feat_channel_raw = M_channel @ X (recnet.py:410), flip + cat (:416-417)
@@ -505,11 +521,27 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     const Lin* ln = t->lin;
     RC(lin_backward(h, t, w, ln[5], t->dMc, 512, c.h3, 64, crow, t->d32a, 64, st));
     HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h3pre, 64, 64, t->a[2], crow, t->rowdot, t->ga[2], 1, st));
-    RC(lin_backward(h, t, w, ln[4], t->d32a, 64, c.t5, 512, crow, t->dt, 512, st));
-    RC(lin_backward(h, t, w, ln[3], t->dt, 512, c.h2, 64, crow, t->d32b, 64, st));
+    // a folded pair: gradient of the 32x32 product, then its adjoint onto the two linears
+    auto pair_backward = [&](int q, const Lin& lb, const Lin& la, const float* dy, const float* x, float* dx) -> int {
+        Lin f;
+        f.in = 32; f.out = 32; f.in_pad = 32; f.out_pad = 64; f.w = t->foldA[q]; f.b = t->foldd[q]; f.gw = t->gfoldA; f.gb = t->gfoldd;
+        HIPCK(h, hipMemsetAsync(t->gfoldA, 0, 64 * 32 * sizeof(float), st));
+        HIPCK(h, hipMemsetAsync(t->gfoldd, 0, 64 * sizeof(float), st));
+        RC(lin_backward(h, t, w, f, dy, 64, x, 64, crow, dx, 64, st));
+        HIPCK(h, launch_ch_unfold(t->gfoldA, t->gfoldd, lb.w, la.w, la.b, lb.gw, lb.gb, la.gw, la.gb, st));
+        return FFR_OK;
+    };
+    if (c.folded) RC(pair_backward(1, ln[4], ln[3], t->d32a, c.h2, t->d32b));
+    else {
+        RC(lin_backward(h, t, w, ln[4], t->d32a, 64, c.t5, 512, crow, t->dt, 512, st));
+        RC(lin_backward(h, t, w, ln[3], t->dt, 512, c.h2, 64, crow, t->d32b, 64, st));
+    }
     HIPCK(h, launch_prelu_rows_bwd(t->d32b, c.h2pre, 64, 64, t->a[1], crow, t->rowdot, t->ga[1], 1, st));
-    RC(lin_backward(h, t, w, ln[2], t->d32b, 64, c.t2, 512, crow, t->dt, 512, st));
-    RC(lin_backward(h, t, w, ln[1], t->dt, 512, c.h1, 64, crow, t->d32a, 64, st));
+    if (c.folded) RC(pair_backward(0, ln[2], ln[1], t->d32b, c.h1, t->d32a));
+    else {
+        RC(lin_backward(h, t, w, ln[2], t->d32b, 64, c.t2, 512, crow, t->dt, 512, st));
+        RC(lin_backward(h, t, w, ln[1], t->dt, 512, c.h1, 64, crow, t->d32a, 64, st));
+    }
     HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h1pre, 64, 64, t->a[0], crow, t->rowdot, t->ga[0], 1, st));
     RC(lin_backward(h, t, w, ln[0], t->d32a, 64, c.cat, 576, crow, nullptr, 0, st));
     // ---- M_space: feat_space = X_flat @ M_space ------------------------------------------------
@@ -870,6 +902,7 @@ int ffr_train_option(ffr_handle* h, const char* name, int value) {
     RC(get_train(h, &t));
     if (!name) return fail(h, FFR_ERR_ARG, "ffr_train_option: null name");
     if (std::string(name) == "winograd") { t->sc.wino = value != 0; return FFR_OK; }
+    if (std::string(name) == "fold_channel") { t->sc.fold = value != 0; return FFR_OK; }
     return fail(h, FFR_ERR_KEY, "ffr_train_option: unknown option '%s'", name);
 }
 

@@ -89,6 +89,15 @@ hipError_t launch_prelu_rows(const float* x, float* out, int pitch, int C, const
 // dx = dy * (x > 0 ? 1 : slope[row % 512]) in place over dy; dslope[c] (+)= sum_{n,o} dy*min(x,0); rowdot: scratch [rows]
 hipError_t launch_prelu_rows_bwd(float* dy, const float* x, int pitch, int C, const float* slope, long long rows,
                                  float* rowdot, float* dslope, int accumulate, hipStream_t stream);
+// Linear(32,512) followed directly by Linear(512,32) (Conv4Channel.2/.3 and .5/.6, models/recnet.py:376-380) is one
+// 32x32 map: A[o][i] = sum_k Wb[o][k] Wa[k][i], d[o] = bb[o] + sum_k Wb[o][k] ba[k]   (Wb [64][512] rows >= 32 zero,
+// Wa [512][32]); A is [64][32], d [64], rows >= 32 zero.  Exact algebra; the 512-wide intermediate never exists.
+hipError_t launch_ch_fold(const float* Wb, const float* bb, const float* Wa, const float* ba, float* A, float* d,
+                          hipStream_t stream);
+// adjoint: gWb[o][k] += sum_i dA[o][i] Wa[k][i] + dd[o] ba[k];  gbb[o] += dd[o];
+//          gWa[k][i] += sum_o Wb[o][k] dA[o][i];                gba[k] += sum_o Wb[o][k] dd[o]
+hipError_t launch_ch_unfold(const float* dA, const float* dd, const float* Wb, const float* Wa, const float* ba, float* gWb,
+                            float* gbb, float* gWa, float* gba, hipStream_t stream);
 // raw[n][c][p] (pitch 64) -> bufF[n*49 + p][512 + c] and bufF[n*49 + flipW(p)][c]   (recnet.py:416-417)
 hipError_t launch_raw_to_cat(const float* raw, float* bufF, int imgs, hipStream_t stream);
 // adjoint: draw[n][c][p] = dF[n*49+p][512+c] + dF[n*49+flipW(p)][c], zeros for p >= 49

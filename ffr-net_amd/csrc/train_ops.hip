@@ -595,6 +595,67 @@ hipError_t launch_prelu_rows_bwd(float* dy, const float* x, int pitch, int C, co
     return hipGetLastError();
 }
 
+// 64 x 32 outputs (+ 64 biases), one thread each, K = 512
+__global__ __launch_bounds__(256) void k_ch_fold(const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                const float* __restrict__ Wa, const float* __restrict__ ba,
+                                                float* __restrict__ A, float* __restrict__ d) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < 64 * 32) {
+        const int o = idx >> 5, i = idx & 31;
+        float s = 0.f;
+        if (o < 32)
+            for (int k = 0; k < 512; ++k) s += Wb[o * 512 + k] * Wa[k * 32 + i];
+        A[idx] = s;
+    } else if (idx < 64 * 32 + 64) {
+        const int o = idx - 64 * 32;
+        float s = 0.f;
+        if (o < 32) {
+            s = bb[o];
+            for (int k = 0; k < 512; ++k) s += Wb[o * 512 + k] * ba[k];
+        }
+        d[o] = s;
+    }
+}
+
+hipError_t launch_ch_fold(const float* Wb, const float* bb, const float* Wa, const float* ba, float* A, float* d,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(k_ch_fold, dim3(9), dim3(256), 0, stream, Wb, bb, Wa, ba, A, d);
+    return hipGetLastError();
+}
+
+// thread per (o, k) for gWb and per (k, i) for gWa; the bias gradients ride along
+__global__ __launch_bounds__(256) void k_ch_unfold(const float* __restrict__ dA, const float* __restrict__ dd,
+                                                  const float* __restrict__ Wb, const float* __restrict__ Wa,
+                                                  const float* __restrict__ ba, float* __restrict__ gWb,
+                                                  float* __restrict__ gbb, float* __restrict__ gWa,
+                                                  float* __restrict__ gba) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < 32 * 512) {                       // gWb[o][k], lanes along k
+        const int o = idx >> 9, k = idx & 511;
+        float s = dd[o] * ba[k];
+        for (int i = 0; i < 32; ++i) s += dA[o * 32 + i] * Wa[k * 32 + i];
+        gWb[o * 512 + k] += s;
+        if (k == 0) gbb[o] += dd[o];
+    } else if (idx < 2 * 32 * 512) {            // gWa[k][i], lanes along i
+        const int j = idx - 32 * 512;
+        const int k = j >> 5, i = j & 31;
+        float s = 0.f, sb = 0.f;
+        for (int o = 0; o < 32; ++o) {
+            const float w = Wb[o * 512 + k];
+            s += w * dA[o * 32 + i];
+            sb += w * dd[o];
+        }
+        gWa[k * 32 + i] += s;
+        if (i == 0) gba[k] += sb;
+    }
+}
+
+hipError_t launch_ch_unfold(const float* dA, const float* dd, const float* Wb, const float* Wa, const float* ba, float* gWb,
+                            float* gbb, float* gWa, float* gba, hipStream_t stream) {
+    hipLaunchKernelGGL(k_ch_unfold, dim3(2 * 32 * 512 / 256), dim3(256), 0, stream, dA, dd, Wb, Wa, ba, gWb, gbb, gWa, gba);
+    return hipGetLastError();
+}
+
 // block per (image, 32-channel group)
 __global__ __launch_bounds__(256) void k_raw_to_cat(const float* __restrict__ raw, float* __restrict__ bufF) {
     __shared__ float t[32][65];

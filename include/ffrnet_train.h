@@ -105,7 +105,10 @@ int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, do
 
 /* Options of the training state. "winograd" (default 1): the 3x3 convolutions of the forward and of the data
  * gradient with >= 128 input channels run as Winograd F(4x4,3x3) (weights transformed on the device from the
- * live master weights at every use); 0 = direct implicit GEMM everywhere.                               */
+ * live master weights at every use); 0 = direct implicit GEMM everywhere.  "fold_channel" (default 1): the
+ * Linear(32,512) -> Linear(512,32) pairs of Conv4Channel (models/recnet.py:376-380) run as their 32x32 product
+ * (exact algebra; gradients are mapped back onto the four tensors); 0 = the 512-wide intermediates are formed
+ * as the reference does.                                                                                */
 int ffr_train_option(ffr_handle* h, const char* name, int value);
 
 /* Test hook: the first n floats of a named intermediate buffer of context `slot` (forward activations:
