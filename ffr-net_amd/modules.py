@@ -222,10 +222,10 @@ class RecNet(_NativeModule):
         if ent is None:
             eng = Engine(device.index)
             eng.train_init({k: v.detach() for k, v in sd.items()})
-            ent = [eng, {k: (id(v), v._version) for k, v in sd.items()}, 0]
+            ent = [eng, {k: (id(v), v._version) for k, v in sd.items()}, 0, [None, None]]
             cache[('train', device.index)] = ent
             return ent
-        eng, seen, _ = ent
+        eng, seen = ent[0], ent[1]
         for k, v in sd.items():
             sig = (id(v), v._version)
             if seen.get(k) == sig or k.endswith('num_batches_tracked'):
@@ -245,11 +245,14 @@ class RecNet(_NativeModule):
             raise RuntimeError('ffrnet_amd.RecNet: input must be a float32 ROCm device tensor; this package has no CPU path')
         ent = self._train_engine(input.device)
         eng = ent[0]
-        slot = ent[2] % 2
+        # two activation contexts: the reference keeps exactly two forwards alive (clean, occluded) until backward
+        ticket = ent[2]
+        slot = ticket % 2
         ent[2] += 1
+        ent[3][slot] = ticket
         names = [k for k, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
-        outs = _RecNetTrainFn.apply(eng, slot, names, input, label, *params)
+        outs = _RecNetTrainFn.apply(eng, (slot, ticket, ent[3]), names, input, label, *params)
         # BatchNorm buffers follow the native running statistics (models/recnet.py:141-143 in train mode)
         with torch.no_grad():
             seen = ent[1]
@@ -268,14 +271,18 @@ class _RecNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, slot, names, input, label, *params):
-        ctx.eng, ctx.slot, ctx.names = eng, slot, names
+        ctx.eng, ctx.names = eng, names
+        ctx.slot, ctx.ticket, ctx.live = slot
         ctx.shapes = [tuple(p.shape) for p in params]
-        outs = eng.train_forward(input.detach(), label, groups=1, slot=slot)
+        outs = eng.train_forward(input.detach(), label, groups=1, slot=ctx.slot)
         return outs
 
     @staticmethod
     def backward(ctx, *gouts):
         eng = ctx.eng
+        if ctx.live[ctx.slot] != ctx.ticket:
+            raise RuntimeError('ffrnet_amd.RecNet: the activations of this forward were overwritten -- at most two '
+                               'train-mode forwards may be outstanding before backward (models/trainer.py:144-145)')
         eng.train_zero_grad()
         eng.train_backward([g if g is not None else None for g in gouts], slot=ctx.slot)
         grads = []
