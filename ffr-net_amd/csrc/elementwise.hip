@@ -6,6 +6,7 @@
 namespace ffr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -15,9 +16,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------
 // Stem: Conv3x3(3->64, pad 1, no bias) + BN + PReLU   (pretrain/model_ir_se50.py:118-120)
-// Block = 256 threads = 16 channel quads x 16 pixel groups; 64 pixels per step, 4 pixels
-// per thread; the 4x27 weights of a thread's channel quad stay in registers, the 27-tap
-// patches of the 64 pixels are staged in LDS ([pix][28]) and read as 7 b128 per pixel.
+// Block = 256 threads; 64 pixels per step: the 27-tap patches are staged in LDS ([pix][28], slot 27 = 0) by
+// 4 threads per pixel, then the [64 px x 28] x [28 x 64 ch] product runs on the matrix cores
+// (v_mfma_f32_32x32x2_f32, one 32x32 output tile per wave, 14 k-steps): the weights of a wave's 32
+// channels stay in 14 registers per lane, bias + PReLU on the accumulator, 128-byte NHWC stores.
 // ---------------------------------------------------------------------------------------
 #define STEM_PIX 64
 #define STEM_STEPS 8
@@ -33,14 +35,18 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
                                              const float* __restrict__ x2, int n_split) {
     __shared__ __attribute__((aligned(16))) float patch[STEM_PIX * 28];
     const int tid = threadIdx.x;
-    const int cg = tid & 15, pg = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int mt = wave >> 1, nt = wave & 1;          // this wave's 32-pixel x 32-channel output tile
+    const int half = lane >> 5, ch = nt * 32 + (lane & 31);
     const int HW = H * W;
     const long long total = (long long)N * HW;
-    f32x4 wr[27];
+    float wr[14];                                      // B operand: w[k = 2 ks + half][ch], k = 27 is the zero pad
 #pragma unroll
-    for (int k = 0; k < 27; ++k) wr[k] = *reinterpret_cast<const f32x4*>(w + k * 64 + cg * 4);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + cg * 4);
-    const f32x4 sl = *reinterpret_cast<const f32x4*>(slope + cg * 4);
+    for (int ks = 0; ks < 14; ++ks) {
+        const int k = 2 * ks + half;
+        wr[ks] = k < 27 ? w[k * 64 + ch] : 0.f;
+    }
+    const float b = bias[ch], sl = slope[ch];
 
     int f_ci[7], f_dr[7], f_ds[7];          // tap geometry of this thread's 7 fill slots
 #pragma unroll
@@ -50,58 +56,57 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
         f_dr[i] = (k - f_ci[i] * 9) / 3 - 1;
         f_ds[i] = k % 3 - 1;
     }
+    // fill: 4 threads per pixel, 7 taps each (k = (ci*3 + r)*3 + s, k == 27 is padding): ONE pixel decomposition
+    // per thread and step; the tap geometry of a thread never changes.  The values of step s + 1 are fetched
+    // into registers while step s multiplies.
+    float nv[7];
+    auto fetch = [&](int step) {
+        const long long p = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX + (tid >> 2);
+        const bool pv = p < total;
+        const int n = pv ? (int)(p / HW) : 0;
+        const int rem = pv ? (int)(p - (long long)n * HW) : 0;
+        const int h = rem / W, wq = rem - h * W;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            float v = 0.f;
+            const int hi = h + f_dr[i], wi = wq + f_ds[i];
+            if (pv && f_ci[i] < 3 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+                if (U8) {
+                    const int ws = (flip && flip[n]) ? W - 1 - wi : wi;
+                    const float u = (float)xu8[(((long long)n * H + hi) * W + ws) * 3 + (2 - f_ci[i])];
+                    v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.5f), 0.5f);
+                } else {
+                    // images [n_split, N) come from a second buffer (clean | occluded halves of a training batch)
+                    const float* xs = n >= n_split ? x2 : x;
+                    const int nn = n >= n_split ? n - n_split : n;
+                    v = xs[((long long)(nn * 3 + f_ci[i]) * H + hi) * W + wi];
+                }
+            }
+            nv[i] = v;
+        }
+    };
+    fetch(0);
     for (int step = 0; step < STEM_STEPS; ++step) {
         const long long p0 = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX;
         if (p0 >= total) break;
         __syncthreads();
-        // fill: 4 threads per pixel, 7 taps each (k = (ci*3 + r)*3 + s, k == 27 is padding): ONE pixel
-        // decomposition per thread and step; the tap geometry of a thread never changes
-        {
-            const int pix = tid >> 2;
-            const long long p = p0 + pix;
-            const bool pv = p < total;
-            const int n = pv ? (int)(p / HW) : 0;
-            const int rem = pv ? (int)(p - (long long)n * HW) : 0;
-            const int h = rem / W, wq = rem - h * W;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                float v = 0.f;
-                const int hi = h + f_dr[i], wi = wq + f_ds[i];
-                if (pv && f_ci[i] < 3 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
-                    if (U8) {
-                        const int ws = (flip && flip[n]) ? W - 1 - wi : wi;
-                        const float u = (float)xu8[(((long long)n * H + hi) * W + ws) * 3 + (2 - f_ci[i])];
-                        v = __fdiv_rn(__fsub_rn(__fdiv_rn(u, 255.0f), 0.5f), 0.5f);
-                    } else {
-                        // images [n_split, N) come from a second buffer (clean | occluded halves of a training batch)
-                        const float* xs = n >= n_split ? x2 : x;
-                        const int nn = n >= n_split ? n - n_split : n;
-                        v = xs[((long long)(nn * 3 + f_ci[i]) * H + hi) * W + wi];
-                    }
-                }
-                patch[pix * 28 + (tid & 3) * 7 + i] = v;
-            }
-        }
+        for (int i = 0; i < 7; ++i) patch[(tid >> 2) * 28 + (tid & 3) * 7 + i] = nv[i];
         __syncthreads();
+        if (step + 1 < STEM_STEPS) fetch(step + 1);
+        f32x16 acc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int pix = pg * 4 + q;
-            const long long p = p0 + pix;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const f32x4* pp = reinterpret_cast<const f32x4*>(patch + pix * 28);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* pa = patch + (mt * 32 + (lane & 31)) * 28 + half;
 #pragma unroll
-            for (int k4 = 0; k4 < 7; ++k4) {
-                const f32x4 v = pp[k4];
+        for (int ks = 0; ks < 14; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * ks], wr[ks], acc, 0, 0, 0);
+        // accumulator: channel = lane & 31 (+ 32 nt), pixel row = (r & 3) + 8 (r >> 2) + 4 half
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = k4 * 4 + e;
-                    if (k < 27) acc += v[e] * wr[k];
-                }
-            }
-            acc += b;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] >= 0.f ? acc[e] : acc[e] * sl[e];
-            if (p < total) *reinterpret_cast<f32x4*>(out + p * 64 + cg * 4) = acc;
+        for (int r = 0; r < 16; ++r) {
+            const long long p = p0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[r] + b;
+            v = v >= 0.f ? v : v * sl;
+            if (p < total) out[p * 64 + ch] = v;
         }
     }
 }
