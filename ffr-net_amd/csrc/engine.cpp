@@ -104,7 +104,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     RC(upload(h, owner, wp, &L->w));
     RC(upload(h, owner, bias, &L->bias));
     L->wu = nullptr;
-    static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 128;
+    static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 64;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
         // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
         static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -385,6 +385,8 @@ Work layout(char* base, int N, int H, int W) {
     {
         auto tiles = [&](int div) { return (size_t)N * ((H / div + 3) / 4) * ((W / div + 3) / 4); };
         size_t cap = 36 * tiles(2) * 128;                                   // 56x56, 64 -> 128 channels
+        static const bool wino_112 = !(getenv("FFR_WINO_112") && atoi(getenv("FFR_WINO_112")) == 0);
+        if (wino_112 && 36 * tiles(1) * 64 > cap) cap = 36 * tiles(1) * 64;   // 112x112, 64 -> 64 (first bottleneck)
         if (36 * tiles(4) * 256 > cap) cap = 36 * tiles(4) * 256;           // 28x28, 128 -> 256
         if (36 * tiles(8) * 512 > cap) cap = 36 * tiles(8) * 512;           // 14x14, 256 -> 512
         if (36 * tiles(16) * 1536 > cap) cap = 36 * tiles(16) * 1536;       // 7x7, RecNet 1536 -> 512
@@ -466,7 +468,8 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         bool pooled = false;
         const int tiles = ((ho + 3) / 4) * ((wo + 3) / 4);
         static const bool se_fuse = !(getenv("FFR_SE_FUSE") && atoi(getenv("FFR_SE_FUSE")) == 0);
-        if (se_fuse && b.stride == 1 && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
+        // (beyond 64 tiles per image k_se_fc would spend more on adding partials than the separate pooling pass costs)
+        if (se_fuse && b.stride == 1 && tiles <= 64 && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
         RC(run_conv(h, b.c2, c2, st));
