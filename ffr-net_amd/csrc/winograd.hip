@@ -1,5 +1,5 @@
 // Winograd F(4x4, 3x3) data transforms around the batched fp32-MFMA GEMM (igemm.hip) for the
-// 3x3 / stride 1 / pad 1 convolutions with >= 256 input channels (reference
+// 3x3 / stride 1 / pad 1 convolutions with >= 64 input channels (reference
 // pretrain/model_ir_se50.py:67,69 in stages 3-4 and models/recnet.py:65,82).
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        (Lavin & Gray 2016, F(4x4,3x3))
