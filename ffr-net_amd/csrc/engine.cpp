@@ -284,7 +284,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // 256 MiB Infinity Cache between the transform that writes them and the kernel that reads them
             static const long long slice_mb = getenv("FFR_WINO_SLICE_MB") ? atoll(getenv("FFR_WINO_SLICE_MB")) : 0;
             int nslice = 1;
-            if (slice_mb > 0) {
+            if (slice_mb > 0 && c.wino_stage == 0) {
                 const double mb = 36.0 * T * (L.cin_pad + L.cout_pad) * 4.0 / 1048576.0;
                 while (nslice < c.N && mb / nslice > (double)slice_mb) ++nslice;
                 while (c.N % nslice) ++nslice;
@@ -295,7 +295,8 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 const float* xs = c.x + (size_t)sl * Ns * c.H * c.W * c.in_pitch;
                 const float* rs = c.resid ? c.resid + (size_t)sl * Ns * c.H * c.W * c.res_pitch : nullptr;
                 float* os = c.out + (size_t)sl * Ns * c.H * c.W * c.out_pitch;
-                {
+                if (c.took_wino) *c.took_wino = true;
+                if (c.wino_stage != 2) {
                     Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)Ns * c.H * c.W * L.cin + 36.0 * Ts * L.cin_pad));
                     HIPCK(h, launch_wino_in(xs, c.winoV, Ns, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
                 }
@@ -351,6 +352,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
                 RC(run_gemm(h, g, c, flops / nslice, bytes / nslice, st));
                 }
+                if (c.wino_stage == 1) continue;        // the caller transforms M itself (k_wino_out_in)
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * Ts * L.cout_pad + (double)M / nslice * L.cout));
                 const bool sums = c.tile_sums && nslice == 1;
                 HIPCK(h, launch_wino_out(c.winoM, L.bias, L.slope, rs, c.res_pitch, os, c.out_pitch, c.out_coff,
@@ -458,7 +460,20 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         c1.x = cur; c1.N = N; c1.H = ch; c1.W = cw; c1.in_pitch = b.cin;
         c1.out = w.t1; c1.out_pitch = b.depth; c1.cout_store = b.depth;
         c1.partial = w.partial; c1.partial_cap = w.partial_cap; c1.tickets = w.tickets; c1.tickets_cap = w.tickets_cap; c1.winoV = w.winoV; c1.winoM = w.winoM; c1.wino_cap = w.wino_cap;
+        // conv1 -> conv2 without the activation round trip when both run as Winograd on a map of <= 4x4 tiles
+        static const bool oi_fuse = !(getenv("FFR_WINO_OI") && atoi(getenv("FFR_WINO_OI")) == 0);
+        const long long Tt = (long long)N * ((ch + 3) / 4) * ((cw + 3) / 4);
+        bool chained = false;
+        if (oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
+            wino_out_in_supported(ch, cw, b.c1.cout_pad) && (size_t)36 * Tt * b.c1.cout_pad <= w.wino_cap &&
+            (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
+            c1.wino_stage = 1; c1.took_wino = &chained;
+        }
         RC(run_conv(h, b.c1, c1, st));
+        if (chained) {
+            Scope s(h, st, FFR_KC_WINO, 0, 4.0 * 72.0 * Tt * b.c1.cout_pad);
+            HIPCK(h, launch_wino_out_in(w.winoM, b.c1.bias, b.c1.slope, w.winoV, N, ch, cw, b.c1.cout_pad, b.c1.border, st));
+        }
         ConvCall c2{};
         c2.x = w.t1; c2.N = N; c2.H = ch; c2.W = cw; c2.in_pitch = b.depth;
         c2.out = w.res; c2.out_pitch = b.depth; c2.cout_store = b.depth;
@@ -472,6 +487,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         if (se_fuse && b.stride == 1 && tiles <= 64 && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
+        if (chained) c2.wino_stage = 2;
         RC(run_conv(h, b.c2, c2, st));
         {
             const double e = (double)N * ho * wo * b.depth;

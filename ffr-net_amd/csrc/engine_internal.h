@@ -147,6 +147,8 @@ struct ConvCall {
     int* tickets; size_t tickets_cap;
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
     int wino_mode = -1;                            // -1 auto (env FFR_WINO), 0 never, 1 whenever packed
+    int wino_stage = 0;                            // 0 whole conv; 1 stop after the GEMM (M stays in winoM); 2 V is ready in winoV
+    bool* took_wino = nullptr;                     // set to true when the Winograd path ran
     float* tile_sums = nullptr;                    // Winograd path only: per-tile sums of the stored outputs [T][cout_pad]
     bool* tile_sums_written = nullptr;             // set to true when the Winograd path wrote them
 };

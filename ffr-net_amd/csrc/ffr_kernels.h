@@ -57,6 +57,11 @@ hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad
 // weight gradient in the Winograd domain: dM[36][T][Cp] = A dy A^T per 4x4 output tile; grad[o][9][i] (+)= G^T dU G
 hipError_t launch_wino_dout(const float* dy, float* dM, int N, int H, int W, int Cp, hipStream_t stream);
 hipError_t launch_wino_dweights(const float* dU, float* grad, int out_pad, int in_pad, int accumulate, hipStream_t stream);
+// conv1 -> conv2 inside one bottleneck on maps of at most 4x4 tiles: V2 = B^T PReLU(A^T M1 A + bias) B per image, the
+// activation stays in LDS
+bool wino_out_in_supported(int H, int W, int C);
+hipError_t launch_wino_out_in(const float* M, const float* bias, const float* slope, float* V, int N, int H, int W, int C,
+                              int border_bias, hipStream_t stream);
 // out = epilogue(A^T M A): bias[(border class)][cout_pad], PReLU, residual, sigmoid (flags bit0)
 hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
                            float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,

@@ -307,6 +307,116 @@ hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pit
     return hipGetLastError();
 }
 
+// ---- conv1 -> conv2 of a bottleneck without the activation round trip -------------------------------------
+// For maps of at most 4x4 tiles (14x14, 7x7) one block holds a whole image x CB channels: phase 1 is the output
+// transform of conv1 (bias by border class, PReLU) into an LDS image, phase 2 the input transform of conv2 (zero
+// padding) out of it.  M1[36][T][C] -> V2[36][T][C]; the activation itself is never written (only conv2 reads it,
+// pretrain/model_ir_se50.py:66-70).
+struct WinoOutInArgs {
+    const float* M; const float* bias; const float* slope; float* V;
+    int H, W, C, th, tw, border_bias;
+    long long T;
+};
+
+template <int TILES>      // tiles per image: 16 (up to 16x16) or 4 (up to 8x8)
+__global__ __launch_bounds__(256) void k_wino_out_in(const WinoOutInArgs a) {
+    constexpr int QUADS = 256 / TILES;            // channel quads per block
+    constexpr int CB = QUADS * 4;
+    extern __shared__ __attribute__((aligned(16))) float act[];      // [H*W][CB]
+    const int n = blockIdx.y, c0 = blockIdx.x * CB;
+    const int q = threadIdx.x % QUADS, tl = threadIdx.x / QUADS;
+    const int tx = tl % a.tw, ty = tl / a.tw;
+    const bool live = tl < a.th * a.tw;
+    const int c4 = c0 + q * 4;
+    const long long t = (long long)n * a.th * a.tw + tl;
+    const size_t plane = (size_t)a.T * a.C;
+    if (live) {
+        const float* min = a.M + (size_t)t * a.C + c4;
+        f32x4 tmp[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            f32x4 m[6], y[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(min + (size_t)(i * 6 + j) * plane);
+            at6(m, y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tmp[i][j] = y[i];
+        }
+        f32x4 slope4 = {1.f, 1.f, 1.f, 1.f};
+        if (a.slope) slope4 = *reinterpret_cast<const f32x4*>(a.slope + c4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 y[4];
+            at6(tmp[i], y);
+            const int oh = ty * 4 + i;
+            if (oh >= a.H) continue;
+            const int rc = !a.border_bias ? 0 : (oh == 0 ? 0 : (oh == a.H - 1 ? 2 : 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ow = tx * 4 + j;
+                if (ow >= a.W) continue;
+                const int cls = !a.border_bias ? 0 : rc * 3 + (ow == 0 ? 0 : (ow == a.W - 1 ? 2 : 1));
+                f32x4 v = y[j] + *reinterpret_cast<const f32x4*>(a.bias + (size_t)cls * a.C + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * slope4[e];
+                *reinterpret_cast<f32x4*>(act + ((size_t)oh * a.W + ow) * CB + q * 4) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const int h0 = ty * 4 - 1, w0 = tx * 4 - 1;
+    f32x4 tmp[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 d[6], v[6];
+        const int wi = w0 + j;
+        const bool okw = (unsigned)wi < (unsigned)a.W;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int hi = h0 + i;
+            d[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (okw && (unsigned)hi < (unsigned)a.H) d[i] = *reinterpret_cast<const f32x4*>(act + ((size_t)hi * a.W + wi) * CB + q * 4);
+        }
+        bt6(d, v);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][j] = v[i];
+    }
+    float* vout = a.V + (size_t)t * a.C + c4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 v[6];
+        bt6(tmp[i], v);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (size_t)(i * 6 + j) * plane) = v[j];
+    }
+}
+
+bool wino_out_in_supported(int H, int W, int C) {
+    const int tiles = ((H + 3) / 4) * ((W + 3) / 4);
+    if (tiles > 16) return false;
+    const int cb = tiles > 4 ? 64 : 256;
+    return C % cb == 0 && (size_t)H * W * cb * 4 <= 64 * 1024;
+}
+
+hipError_t launch_wino_out_in(const float* M, const float* bias, const float* slope, float* V, int N, int H, int W, int C,
+                              int border_bias, hipStream_t stream) {
+    if (!wino_out_in_supported(H, W, C)) return hipErrorInvalidValue;
+    WinoOutInArgs a;
+    a.M = M; a.bias = bias; a.slope = slope; a.V = V; a.H = H; a.W = W; a.C = C; a.border_bias = border_bias;
+    a.th = (H + 3) / 4; a.tw = (W + 3) / 4;
+    a.T = (long long)N * a.th * a.tw;
+    const int tiles = a.th * a.tw;
+    if (tiles > 4) {
+        const size_t lds = (size_t)H * W * 64 * 4;
+        hipLaunchKernelGGL(k_wino_out_in<16>, dim3(C / 64, N), dim3(256), lds, stream, a);
+    } else {
+        const size_t lds = (size_t)H * W * 256 * 4;
+        hipLaunchKernelGGL(k_wino_out_in<4>, dim3(C / 256, N), dim3(256), lds, stream, a);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_wino_out(const float* M, const float* bias, const float* slope, const float* resid, int res_pitch,
                            float* out, int out_pitch, int out_coff, int cout_store, int cout_pad, int N, int H, int W,
                            int border_bias, int flags, hipStream_t stream, float* tile_sums) {
