@@ -157,12 +157,19 @@ def main():
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run '
                              '--nproc-per-node %d' % (args.gpus, args.gpus))
     dist = None
+    # FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1: every rank on cuda:0 over gloo -- exercises the N > 1 code path
+    # on a 1-GPU box (RCCL refuses two ranks on one device); timings of such a run mean nothing
+    backend = os.environ.get('FFR_BENCH_BACKEND', 'nccl')
+    if os.environ.get('FFR_BENCH_ONE_DEVICE') == '1':
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device('cuda', local)
     if args.workload == 'train':
         return train_workload(args, world, rank, local, dist)

@@ -372,3 +372,25 @@ def test_hipgraph_replay_matches_eager(engine):
     h_new, _ = g(x2)
     e_new, _ = engine.embed(x2)
     assert torch.equal(h_new, e_new)
+
+
+def test_bench_and_trainer_two_ranks_on_one_gpu():
+    """The N > 1 code paths on hardware, with what a 1-GPU box allows: two ranks on cuda:0 over gloo (RCCL refuses two
+    ranks on one device).  bench.py: all-gather of the embeddings, barrier, max-over-ranks timing, one JSON line from
+    rank 0 with n_gpus = 2.  NativeTrainer: after one iteration on different batches both ranks hold identical
+    parameters (the zero-copy flat gradient buffer went through the all-reduce)."""
+    import json
+    import subprocess
+    env = dict(os.environ, FFR_BENCH_BACKEND='gloo', FFR_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '16',
+           '--no-roofline', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['global_batch'] == 32 and d['steps'] == 2
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ddp_two_ranks_one_gpu.py')], cwd=root, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])

@@ -1,0 +1,44 @@
+"""Two training processes on ONE GPU with the gloo backend (RCCL refuses two ranks on one device): after an
+iteration on different batches both ranks must hold bitwise identical parameters -- the flat gradient buffer,
+a zero-copy torch view of native device memory, really went through the all-reduce."""
+import json, os, sys
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def worker(rank, world, port, q):
+    import ffrnet_amd
+    from ffrnet_amd import synth
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    specs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g0_state_dict_keys.json')))
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(synth.synth_state_dict(specs['encoder']))
+    tr = ffrnet_amd.NativeTrainer(eng, synth.synth_state_dict(specs['recnet']), lr=1e-3)
+    tr.broadcast_params(0)
+    non, ocl, label = (t.cuda() for t in synth.synth_train_batch(4, seed=700 + rank))
+    items = tr.step(non, ocl, label)
+    torch.cuda.synchronize()
+    p = tr.flat_params.cpu()
+    q.put((rank, [float(x) for x in items], float(p.double().sum()), float(p.double().abs().sum()), p[::100003].tolist()))
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, 2, 29533, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+    print('losses differ (different batches):', res[0][1] != res[1][1])
+    print('parameters identical after the step:', res[0][2:] == res[1][2:])
+    assert res[0][1] != res[1][1] and res[0][2:] == res[1][2:]
+    print('OK')
