@@ -56,6 +56,21 @@ hipError_t launch_bn_bwd(const float* da, int da_pitch, int da_coff, const float
 hipError_t launch_pack_dgrad(const float* W, int cout_pad, int cin_pad, float* Wd, int cinD_pad, hipStream_t stream);
 // canvas[imgs][9][9][Cp]: dy[imgs][7][7][Cp] at offset (1,1), zero border
 hipError_t launch_embed_9x9(const float* dy, float* canvas, int imgs, int Cp, hipStream_t stream);
+// ---- the 9x9 padded data gradient in three pieces (Winograd mode): an 8x8 block by F(4x4,3x3) on a 2x2-tile canvas,
+// the bottom row (p = 8) and the right column (q = 8) as two small GEMMs --------------------------------------------
+// canvas[imgs][8][8][Cp]: dy[imgs][7][7][Cp] at offset (1,1), zero first row / column
+hipError_t launch_embed_8x8(const float* dy, float* canvas, int imgs, int Cp, hipStream_t stream);
+// gathered operands of the two edge GEMMs: Eb[imgs*9][3*Cp] with Eb[q][s*Cp + c] = dy[6][q - s][c],
+// Er[imgs*8][3*Cp] with Er[p][r*Cp + c] = dy[p - r][6][c]   (zero outside the map)
+hipError_t launch_dgrad_edges(const float* dy, float* Eb, float* Er, int imgs, int Cp, hipStream_t stream);
+// their weights from W[cout_pad][9][cin_pad]: Wb[ci][s*cout_pad + co] = W[co][2*3 + s][ci], Wr[ci][r*cout_pad + co] = W[co][r*3 + 2][ci]
+// for ci < rows_out (rows >= cin_pad zero)
+hipError_t launch_pack_dgrad_edges(const float* W, int cout_pad, int cin_pad, float* Wb, float* Wr, int rows_out,
+                                   hipStream_t stream);
+// reflect-pad adjoint reading the three pieces: main[imgs][8][8][p_pitch], bottom[imgs][9][p_pitch], right[imgs][8][p_pitch]
+hipError_t launch_fold_reflect3(const float* main8, const float* bottom, const float* right, int p_pitch, int imgs, int C,
+                                const float* add, int add_pitch, int add_coff, float* out, int out_pitch, int out_coff,
+                                hipStream_t stream);
 // adjoint of ReflectionPad2d(1) on 7x7: dx[img][h][w] = sum of the dxp[img][9][9] entries that read (h, w);
 // out[row][out_coff + c] = fold (+ add[row][add_coff + c])     (C channels, multiples of 4 everywhere)
 hipError_t launch_fold_reflect(const float* dxp, int p_pitch, int imgs, int C, const float* add, int add_pitch,

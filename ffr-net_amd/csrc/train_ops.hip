@@ -296,6 +296,124 @@ hipError_t launch_embed_9x9(const float* dy, float* canvas, int imgs, int Cp, hi
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_embed_8x8(const float* __restrict__ dy, float* __restrict__ canvas, int cq,
+                                                  long long total4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const long long row = idx / cq;
+    const int c = (int)(idx - row * cq);
+    const long long img = row >> 6;
+    const int q = (int)(row & 63);
+    const int qh = (q >> 3) - 1, qw = (q & 7) - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (qh >= 0 && qw >= 0) v = reinterpret_cast<const f32x4*>(dy)[((img * 49) + qh * 7 + qw) * cq + c];
+    reinterpret_cast<f32x4*>(canvas)[idx] = v;
+}
+
+hipError_t launch_embed_8x8(const float* dy, float* canvas, int imgs, int Cp, hipStream_t stream) {
+    if (Cp & 3) return hipErrorInvalidValue;
+    const long long total4 = (long long)imgs * 64 * (Cp >> 2);
+    hipLaunchKernelGGL(k_embed_8x8, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, dy, canvas, Cp >> 2, total4);
+    return hipGetLastError();
+}
+
+// one float4 per thread of Eb (17 rows per image: 9 bottom + 8 right, 3 taps each)
+__global__ __launch_bounds__(256) void k_dgrad_edges(const float* __restrict__ dy, float* __restrict__ Eb, float* __restrict__ Er,
+                                                    int cq, long long total4) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int c = (int)(idx % cq);
+    long long rest = idx / cq;
+    const int tap = (int)(rest % 3); rest /= 3;
+    const int e = (int)(rest % 17);
+    const long long img = rest / 17;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (e < 9) {                      // bottom row p = 8: dy[6][q - s]
+        const int w = e - tap;
+        if ((unsigned)w < 7u) v = reinterpret_cast<const f32x4*>(dy)[((img * 49) + 6 * 7 + w) * cq + c];
+        reinterpret_cast<f32x4*>(Eb)[((img * 9 + e) * 3 + tap) * cq + c] = v;
+    } else {                          // right column q = 8: dy[p - r][6]
+        const int p = e - 9, hh = p - tap;
+        if ((unsigned)hh < 7u) v = reinterpret_cast<const f32x4*>(dy)[((img * 49) + hh * 7 + 6) * cq + c];
+        reinterpret_cast<f32x4*>(Er)[((img * 8 + p) * 3 + tap) * cq + c] = v;
+    }
+}
+
+hipError_t launch_dgrad_edges(const float* dy, float* Eb, float* Er, int imgs, int Cp, hipStream_t stream) {
+    if (Cp & 3) return hipErrorInvalidValue;
+    const long long total4 = (long long)imgs * 17 * 3 * (Cp >> 2);
+    hipLaunchKernelGGL(k_dgrad_edges, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, dy, Eb, Er, Cp >> 2, total4);
+    return hipGetLastError();
+}
+
+// 32x32 (co, ci) tiles through LDS, as k_pack_dgrad; blockIdx.z = which of the 6 taps (3 bottom, 3 right)
+__global__ __launch_bounds__(256) void k_pack_dgrad_edges(const float* __restrict__ W, int cout_pad, int cin_pad,
+                                                         float* __restrict__ Wb, float* __restrict__ Wr, int rows_out) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z;
+    const int k = z % 3;
+    const int t = z < 3 ? 2 * 3 + k : k * 3 + 2;        // bottom: (r = 2, s = k); right: (r = k, s = 2)
+    float* dst = z < 3 ? Wb : Wr;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int ci = ci0 + tx;
+        tile[i][tx] = ci < cin_pad ? W[((size_t)(co0 + i) * 9 + t) * cin_pad + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int ci = ci0 + i;
+        if (ci < rows_out) dst[((size_t)ci * 3 + k) * cout_pad + co0 + tx] = tile[tx][i];
+    }
+}
+
+hipError_t launch_pack_dgrad_edges(const float* W, int cout_pad, int cin_pad, float* Wb, float* Wr, int rows_out,
+                                   hipStream_t stream) {
+    if (cout_pad % 32 || rows_out % 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack_dgrad_edges, dim3(rows_out / 32, cout_pad / 32, 6), dim3(256), 0, stream, W, cout_pad, cin_pad, Wb, Wr,
+                       rows_out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_fold_reflect3(const float* __restrict__ main8, const float* __restrict__ bottom,
+                                                      const float* __restrict__ right, int p_pitch, long long total4, int C,
+                                                      const float* __restrict__ add, int add_pitch, int add_coff,
+                                                      float* __restrict__ out, int out_pitch, int out_coff) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total4) return;
+    const int cq = C >> 2;
+    const long long row = idx / cq;
+    const int c = (int)(idx - row * cq) * 4;
+    const long long img = row / 49;
+    const int p = (int)(row - img * 49);
+    const int h = p / 7, w = p - h * 7;
+    const int nh = (h == 1 || h == 5) ? 2 : 1, nw = (w == 1 || w == 5) ? 2 : 1;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nh; ++a) {
+        const int qh = a == 0 ? h + 1 : (h == 1 ? 0 : 8);
+        for (int bq = 0; bq < nw; ++bq) {
+            const int qw = bq == 0 ? w + 1 : (w == 1 ? 0 : 8);
+            const float* src;
+            if (qh == 8) src = bottom + ((size_t)img * 9 + qw) * p_pitch;
+            else if (qw == 8) src = right + ((size_t)img * 8 + qh) * p_pitch;
+            else src = main8 + ((size_t)img * 64 + qh * 8 + qw) * p_pitch;
+            s += *reinterpret_cast<const f32x4*>(src + c);
+        }
+    }
+    if (add) s += *reinterpret_cast<const f32x4*>(add + row * add_pitch + add_coff + c);
+    *reinterpret_cast<f32x4*>(out + row * out_pitch + out_coff + c) = s;
+}
+
+hipError_t launch_fold_reflect3(const float* main8, const float* bottom, const float* right, int p_pitch, int imgs, int C,
+                                const float* add, int add_pitch, int add_coff, float* out, int out_pitch, int out_coff,
+                                hipStream_t stream) {
+    if ((C | p_pitch | add_pitch | add_coff | out_pitch | out_coff) & 3) return hipErrorInvalidValue;
+    const long long total4 = (long long)imgs * 49 * (C >> 2);
+    hipLaunchKernelGGL(k_fold_reflect3, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, main8, bottom, right, p_pitch,
+                       total4, C, add, add_pitch, add_coff, out, out_pitch, out_coff);
+    return hipGetLastError();
+}
+
 // padded coordinate q in [0,9) reads original refl(q - 1); (h) is read by q = h + 1 and, for h = 1, q = 0,
 // for h = 5, q = 8
 __global__ __launch_bounds__(256) void k_fold_reflect(const float* __restrict__ dxp, int p_pitch, long long total4, int C,
