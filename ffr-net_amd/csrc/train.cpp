@@ -374,7 +374,7 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->sc.dy_floats = rows * 512; t->sc.dy = a.take(t->sc.dy_floats);
         t->sc.slab_floats = (size_t)4 * 512 * 9 * 1536; t->sc.slabs = a.take(t->sc.slab_floats);
         t->sc.U_floats = (size_t)36 * 512 * 1536; t->sc.U = a.take(t->sc.U_floats);
-        t->sc.canvas_floats = imgs * 81 * 512; t->sc.canvas = a.take(t->sc.canvas_floats);
+        t->sc.canvas_floats = imgs * 64 * 512; t->sc.canvas = a.take(t->sc.canvas_floats);
         t->sc.edgeA_floats = imgs * 17 * 3 * 512; t->sc.edgeA = a.take(t->sc.edgeA_floats);
         t->sc.edgeW_floats = (size_t)2 * 1024 * 3 * 512; t->sc.edgeW = a.take(t->sc.edgeW_floats);
         t->sc.edgeO_floats = imgs * 17 * 1024; t->sc.edgeO = a.take(t->sc.edgeO_floats);
@@ -679,7 +679,7 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
     s.dy_floats = (size_t)rows * L.cout_pad; RC(dev_alloc_t(h, own, s.dy_floats, &s.dy));
     s.slab_floats = (size_t)16 * wp.size(); RC(dev_alloc_t(h, own, s.slab_floats, &s.slabs));
     s.U_floats = (size_t)36 * L.cout_pad * (L.cin_pad > need_pad ? L.cin_pad : need_pad); RC(dev_alloc_t(h, own, s.U_floats, &s.U));
-    s.canvas_floats = (size_t)G * N * 81 * L.cout_pad; RC(dev_alloc_t(h, own, s.canvas_floats, &s.canvas));
+    s.canvas_floats = (size_t)G * N * 64 * L.cout_pad; RC(dev_alloc_t(h, own, s.canvas_floats, &s.canvas));
     s.edgeA_floats = (size_t)G * N * 17 * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeA_floats, &s.edgeA));
     s.edgeW_floats = (size_t)2 * need_pad * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeW_floats, &s.edgeW));
     s.edgeO_floats = (size_t)G * N * 17 * need_pad; RC(dev_alloc_t(h, own, s.edgeO_floats, &s.edgeO));

@@ -54,8 +54,6 @@ hipError_t launch_bn_bwd(const float* da, int da_pitch, int da_coff, const float
 // Wd[ci][8 - t][co] = W[co][t][ci]: the rotated / transposed 3x3 weights of the data-gradient convolution.
 // W [cout_pad][9][cin_pad] -> Wd [cinD_pad][9][cout_pad], rows ci >= cin_pad are zero.
 hipError_t launch_pack_dgrad(const float* W, int cout_pad, int cin_pad, float* Wd, int cinD_pad, hipStream_t stream);
-// canvas[imgs][9][9][Cp]: dy[imgs][7][7][Cp] at offset (1,1), zero border
-hipError_t launch_embed_9x9(const float* dy, float* canvas, int imgs, int Cp, hipStream_t stream);
 // ---- the 9x9 padded data gradient in three pieces (Winograd mode): an 8x8 block by F(4x4,3x3) on a 2x2-tile canvas,
 // the bottom row (p = 8) and the right column (q = 8) as two small GEMMs --------------------------------------------
 // canvas[imgs][8][8][Cp]: dy[imgs][7][7][Cp] at offset (1,1), zero first row / column

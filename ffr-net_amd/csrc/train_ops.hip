@@ -273,29 +273,8 @@ hipError_t launch_pack_dgrad(const float* W, int cout_pad, int cin_pad, float* W
     return hipGetLastError();
 }
 
-// canvas[img][1 + h][1 + w][:] = dy[img][h][w][:], zero border: the 7x7 gradient inside the 9x9 map whose
-// 'same' 3x3 convolution is the 9x9 padded data gradient (lets the Winograd path, pad 1 only, compute it)
-__global__ __launch_bounds__(256) void k_embed_9x9(const float* __restrict__ dy, float* __restrict__ canvas, int cq,
-                                                  long long total4) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total4) return;
-    const long long row = idx / cq;
-    const int c = (int)(idx - row * cq);
-    const long long img = row / 81;
-    const int q = (int)(row - img * 81);
-    const int qh = q / 9 - 1, qw = q % 9 - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)qh < 7u && (unsigned)qw < 7u) v = reinterpret_cast<const f32x4*>(dy)[((img * 49) + qh * 7 + qw) * cq + c];
-    reinterpret_cast<f32x4*>(canvas)[idx] = v;
-}
-
-hipError_t launch_embed_9x9(const float* dy, float* canvas, int imgs, int Cp, hipStream_t stream) {
-    if (Cp & 3) return hipErrorInvalidValue;
-    const long long total4 = (long long)imgs * 81 * (Cp >> 2);
-    hipLaunchKernelGGL(k_embed_9x9, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, dy, canvas, Cp >> 2, total4);
-    return hipGetLastError();
-}
-
+// canvas[img][1 + h][1 + w][:] = dy[img][h][w][:] inside an 8x8 map with a zero first row / column: its 'same' 3x3
+// convolution is rows / columns 0..7 of the 9x9 padded data gradient (the Winograd path handles pad 1 only)
 __global__ __launch_bounds__(256) void k_embed_8x8(const float* __restrict__ dy, float* __restrict__ canvas, int cq,
                                                   long long total4) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
