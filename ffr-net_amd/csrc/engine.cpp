@@ -104,6 +104,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     RC(upload(h, owner, wp, &L->w));
     RC(upload(h, owner, bias, &L->bias));
     L->wu = nullptr;
+    L->wuc = nullptr;
     static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 64;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
         // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
@@ -126,6 +127,21 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
             }
         }
         RC(upload(h, owner, wu, &L->wu));
+        // the same weights in the order k_wino_fused streams them (wino_fused.hip: 8-channel K chunks, 16-byte pieces
+        // of one output channel, piece(n, half) = 2 n + (half ^ ((n >> 3) & 1)))
+        const int nkc = L->cin_pad / 8, nbn = L->cout_pad / 64;
+        std::vector<float> wuc(wu.size());
+        for (int nb = 0; nb < nbn; ++nb)
+            for (int kc = 0; kc < nkc; ++kc)
+                for (int xi = 0; xi < 36; ++xi)
+                    for (int nl = 0; nl < 64; ++nl)
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const int piece = 2 * nl + (hf ^ ((nl >> 3) & 1));
+                            float* dst = &wuc[((((size_t)nb * nkc + kc) * 36 + xi) * 128 + piece) * 4];
+                            const float* src = &wu[((size_t)xi * L->cout_pad + nb * 64 + nl) * L->cin_pad + kc * 8 + 4 * hf];
+                            for (int e = 0; e < 4; ++e) dst[e] = src[e];
+                        }
+        RC(upload(h, owner, wuc, &L->wuc));
     }
     L->slope = nullptr;
     if (slope) {
@@ -279,6 +295,53 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         // Winograd F(4x4,3x3): input transform -> 36 batched GEMMs [T x cin] * [cin x cout] -> output transform
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
         const long long T = (long long)c.N * th * tw;
+        // GEMM + output transform in one kernel (wino_fused.hip): M never exists in memory
+        static const bool fused_on = !(getenv("FFR_WINO_FUSED") && atoi(getenv("FFR_WINO_FUSED")) == 0);
+        if (fused_on && L.wuc && c.wino_stage == 0 && wino_chunked_floats(T, L.cin_pad) <= c.wino_cap && T < 0x7fffffffLL) {
+            if (c.took_wino) *c.took_wino = true;
+            {
+                Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
+                HIPCK(h, launch_wino_in_chunked(c.x, c.winoV, c.N, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
+            }
+            WinoFusedArgs f{};
+            f.Vc = c.winoV; f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
+            f.tile_sums = c.tile_sums;
+            f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
+            f.cout_pad = L.cout_pad; f.cout_store = c.cout_store; f.out_pitch = c.out_pitch; f.out_coff = c.out_coff;
+            f.res_pitch = c.res_pitch; f.border_bias = L.border; f.flags = c.flags;
+            const double fexec = 2.0 * 36.0 * (double)((T + 31) / 32 * 32) * (double)L.cout_pad * L.cin_pad;
+            static const bool wf_trace = getenv("FFR_WF_TRACE") != nullptr;
+            if (wf_trace) {     // diagnostics: per-block phase stamps, printed after a stream sync
+                const int nb = wino_fused_blocks(f);
+                unsigned long long* dbuf = nullptr;
+                HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nb * 24 * sizeof(unsigned long long)));
+                HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nb * 24 * sizeof(unsigned long long), st));
+                f.trace = dbuf;
+                HIPCK(h, launch_wino_fused(f, st));
+                HIPCK(h, hipStreamSynchronize(st));
+                std::vector<unsigned long long> tr((size_t)nb * 24);
+                HIPCK(h, hipMemcpy(tr.data(), dbuf, tr.size() * 8, hipMemcpyDeviceToHost));
+                HIPCK(h, hipFree(dbuf));
+                double pro = 0, loop = 0, epi = 0; int cnt = 0;
+                unsigned long long r0 = ~0ull, r1 = 0;
+                for (int b = 0; b < nb; ++b) {
+                    const unsigned long long* q = &tr[(size_t)b * 24];
+                    if (!q[3]) continue;
+                    pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); ++cnt;
+                    if (q[4] > r1) r1 = q[4];
+                    if (q[4] < r0) r0 = q[4];
+                }
+                fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
+                                "epilogue %.0f cyc | block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt,
+                        loop / cnt, loop / cnt / f.nkc, epi / cnt, (double)(r1 - r0) / 100.0);
+                if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
+                return FFR_OK;
+            }
+            Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes, fexec);
+            HIPCK(h, launch_wino_fused(f, st));
+            if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
+            return FFR_OK;
+        }
         if ((size_t)36 * T * L.cin_pad <= c.wino_cap && (size_t)36 * T * L.cout_pad <= c.wino_cap && T < 0x7fffffffLL) {
             // sub-batches: V and M of one slice (36 * tiles * channels * 4 B each) should stay in the
             // 256 MiB Infinity Cache between the transform that writes them and the kernel that reads them
@@ -393,6 +456,7 @@ Work layout(char* base, int N, int H, int W) {
         if (36 * tiles(8) * 512 > cap) cap = 36 * tiles(8) * 512;           // 14x14, 256 -> 512
         if (36 * tiles(16) * 1536 > cap) cap = 36 * tiles(16) * 1536;       // 7x7, RecNet 1536 -> 512
         if (36 * (size_t)N * 9 * 1024 > cap) cap = 36 * (size_t)N * 9 * 1024;  // 9x9 data gradient of the training step, 1024 channels
+        cap += (size_t)36 * 32 * 1536;                                      // k_wino_fused rounds the tile count up to 32
         w.wino_cap = cap;
         w.winoV = a.take(cap);
         w.winoM = a.take(cap);
@@ -464,7 +528,8 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         static const bool oi_fuse = !(getenv("FFR_WINO_OI") && atoi(getenv("FFR_WINO_OI")) == 0);
         const long long Tt = (long long)N * ((ch + 3) / 4) * ((cw + 3) / 4);
         bool chained = false;
-        if (oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
+        static const bool fused_on = !(getenv("FFR_WINO_FUSED") && atoi(getenv("FFR_WINO_FUSED")) == 0);
+        if (!fused_on && oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
             wino_out_in_supported(ch, cw, b.c1.cout_pad) && (size_t)36 * Tt * b.c1.cout_pad <= w.wino_cap &&
             (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
             c1.wino_stage = 1; c1.took_wino = &chained;
@@ -649,6 +714,7 @@ int ffr_create(ffr_handle** out, int device) {
     h->zero = (float*)z;
     hipError_t e = igemm_init();
     if (e == hipSuccess) e = gemm_stream_init();
+    if (e == hipSuccess) e = wino_fused_init();
     if (e != hipSuccess) {
         hipFree(z); delete h;
         return fail(nullptr, FFR_ERR_HIP, "igemm_init: %s", hipGetErrorString(e));

@@ -29,6 +29,7 @@ struct ConvW {
     float* bias = nullptr;
     float* slope = nullptr;
     float* wu = nullptr;     // Winograd F(4,3) weights [36][cout_pad][cin_pad] (G g G^T, BN folded) or null
+    float* wuc = nullptr;    // the same in the K-chunk order k_wino_fused streams ([cout_pad/64][cin_pad/8][36][128][4]) or null
 };
 
 struct Block {

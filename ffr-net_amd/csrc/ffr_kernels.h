@@ -68,6 +68,25 @@ hipError_t launch_wino_out(const float* M, const float* bias, const float* slope
                            int border_bias, int flags, hipStream_t stream, float* tile_sums = nullptr);
 // tile_sums [T][cout_pad] (optional): the sum of every tile's stored outputs -- the SE squeeze partials
 
+// ---- Winograd conv with GEMM and output transform in one kernel (wino_fused.hip) -----------------------------
+// Vc [mbn][nkc][36][64 pieces][4]: the input transform of 32-tile groups in 8-channel K chunks (piece order: see
+// wino_fused.hip); Uc [cout_pad/64][nkc][36][128 pieces][4]: G g G^T in the same chunk order (host packer)
+hipError_t launch_wino_in_chunked(const float* x, float* Vc, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
+                                  hipStream_t stream);
+struct WinoFusedArgs {
+    const float* Vc; const float* Uc;
+    const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
+    int N, H, W, nkc;                       // nkc = cin_pad / 8
+    int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
+    int th, tw, mbn, nbn;                   // filled by the launcher
+    long long T;
+    unsigned long long* trace;              // diagnostics (FFR_WF_TRACE): 6 words per wave, or null
+};
+int wino_fused_blocks(const WinoFusedArgs& a);
+hipError_t wino_fused_init();
+hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream);
+inline size_t wino_chunked_floats(long long T, int cin_pad) { return (size_t)((T + 31) / 32) * 32 * 36 * cin_pad; }
+
 // ---- trunk elementwise (elementwise.hip) -------------------------------------------
 // stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded
 // input: x_nchw fp32, OR (xu8 != null) uint8 [N,H,W,3] RGB images preprocessed on the fly
