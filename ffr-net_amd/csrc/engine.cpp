@@ -127,8 +127,8 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
             }
         }
         RC(upload(h, owner, wu, &L->wu));
-        // the same weights in the order k_wino_fused streams them (wino_fused.hip: 8-channel K chunks, 16-byte pieces
-        // of one output channel, piece(n, half) = 2 n + (half ^ ((n >> 3) & 1)))
+        // the same weights in the order k_wino_fused streams them (wino_fused.hip: 8-channel K chunks, one 16-byte MFMA
+        // fragment per lane: lane = 32 * (k half) + (output channel & 31))
         const int nkc = L->cin_pad / 8, nbn = L->cout_pad / 64;
         std::vector<float> wuc(wu.size());
         for (int nb = 0; nb < nbn; ++nb)
@@ -136,7 +136,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
                 for (int xi = 0; xi < 36; ++xi)
                     for (int nl = 0; nl < 64; ++nl)
                         for (int hf = 0; hf < 2; ++hf) {
-                            const int piece = 2 * nl + (hf ^ ((nl >> 3) & 1));
+                            const int piece = (nl >> 5) * 64 + hf * 32 + (nl & 31);      // = 64 * (32-channel half) + lane
                             float* dst = &wuc[((((size_t)nb * nkc + kc) * 36 + xi) * 128 + piece) * 4];
                             const float* src = &wu[((size_t)xi * L->cout_pad + nb * 64 + nl) * L->cin_pad + kc * 8 + 4 * hf];
                             for (int e = 0; e < 4; ++e) dst[e] = src[e];
@@ -314,26 +314,28 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             if (wf_trace) {     // diagnostics: per-block phase stamps, printed after a stream sync
                 const int nb = wino_fused_blocks(f);
                 unsigned long long* dbuf = nullptr;
-                HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nb * 24 * sizeof(unsigned long long)));
-                HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nb * 24 * sizeof(unsigned long long), st));
+                HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nb * 40 * sizeof(unsigned long long)));
+                HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nb * 40 * sizeof(unsigned long long), st));
                 f.trace = dbuf;
                 HIPCK(h, launch_wino_fused(f, st));
                 HIPCK(h, hipStreamSynchronize(st));
-                std::vector<unsigned long long> tr((size_t)nb * 24);
+                std::vector<unsigned long long> tr((size_t)nb * 40);
                 HIPCK(h, hipMemcpy(tr.data(), dbuf, tr.size() * 8, hipMemcpyDeviceToHost));
                 HIPCK(h, hipFree(dbuf));
-                double pro = 0, loop = 0, epi = 0; int cnt = 0;
+                double pro = 0, loop = 0, epi = 0, ep[5] = {0, 0, 0, 0, 0}; int cnt = 0;
                 unsigned long long r0 = ~0ull, r1 = 0;
                 for (int b = 0; b < nb; ++b) {
-                    const unsigned long long* q = &tr[(size_t)b * 24];
+                    const unsigned long long* q = &tr[(size_t)b * 40];
                     if (!q[3]) continue;
+                    ep[0] += (double)(q[6] - q[2]); ep[1] += (double)(q[7] - q[6]); ep[2] += (double)(q[8] - q[7]);
+                    ep[3] += (double)(q[9] - q[8]); ep[4] += (double)(q[3] - q[9]);
                     pro += (double)(q[1] - q[0]); loop += (double)(q[2] - q[1]); epi += (double)(q[3] - q[2]); ++cnt;
                     if (q[4] > r1) r1 = q[4];
                     if (q[4] < r0) r0 = q[4];
                 }
                 fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
-                                "epilogue %.0f cyc | block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt,
-                        loop / cnt, loop / cnt / f.nkc, epi / cnt, (double)(r1 - r0) / 100.0);
+                                "epilogue %.0f cyc (to LDS %.0f, transform+store %.0f, barrier+to LDS %.0f, transform+store %.0f, end %.0f) | block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt,
+                        loop / cnt, loop / cnt / f.nkc, epi / cnt, ep[0] / cnt, ep[1] / cnt, ep[2] / cnt, ep[3] / cnt, ep[4] / cnt, (double)(r1 - r0) / 100.0);
                 if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
                 return FFR_OK;
             }

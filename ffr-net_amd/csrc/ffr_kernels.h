@@ -80,7 +80,7 @@ struct WinoFusedArgs {
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
     int th, tw, mbn, nbn;                   // filled by the launcher
     long long T;
-    unsigned long long* trace;              // diagnostics (FFR_WF_TRACE): 6 words per wave, or null
+    unsigned long long* trace;              // diagnostics (FFR_WF_TRACE): 10 words per wave, or null
 };
 int wino_fused_blocks(const WinoFusedArgs& a);
 hipError_t wino_fused_init();

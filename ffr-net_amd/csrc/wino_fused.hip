@@ -54,6 +54,15 @@ __device__ __forceinline__ void at6p(const f32x2 m[6], f32x2 y[4]) {
     y[3] = d12 + 8.f * d34 + m[5];
 }
 
+// y = A^T m on four channels
+__device__ __forceinline__ void at6q(const f32x4 m[6], f32x4 y[4]) {
+    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.f * d34;
+    y[2] = s12 + 4.f * s34;
+    y[3] = d12 + 8.f * d34 + m[5];
+}
+
 // y = A^T m (scalar form)
 __device__ __forceinline__ void at6s(const float m[6], float y[4]) {
     const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
@@ -71,10 +80,10 @@ __global__ __launch_bounds__(256) void k_wino_in_c(const float* __restrict__ x, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mb = blockIdx.x, kc = blockIdx.y * 4 + wave;
     const int tl = lane >> 1;
-    const int hh = (lane & 1) ^ ((tl >> 3) & 1);
+    const int hh = lane & 1;
     const long long t = (long long)mb * 32 + tl;
     const int c4 = kc * 8 + hh * 4;
-    float* vout = Vc + (((size_t)mb * nkc + kc) * 36) * 256 + lane * 4;
+    float* vout = Vc + (((size_t)mb * nkc + kc) * 36) * 256 + (hh * 32 + tl) * 4;     // fragment order: lane of k_wino_fused
     if (t >= T) {
 #pragma unroll
         for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(vout + xi * 256) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -144,116 +153,34 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // ---- the fused GEMM + output transform ------------------------------------------------------------------------
-constexpr int WF_SLOT = 768;                 // floats per ring slot: V 256 | U 512
-constexpr int WF_RING = 9 * WF_SLOT;         // per wave
-constexpr int WF_EPI_FLOATS = 36 * 32 * 32;  // the epilogue's E[xi][tile][32 channels] (147,456 B) aliases the rings (110,592 B)
+constexpr int WF_EPI_FLOATS = 36 * 32 * 32;  // the epilogue's E[xi][tile][32 channels] (147,456 B); the K loop uses no LDS
 constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 4) * 4;   // + bias table + tile table = 150,272 B
 
 __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    // block -> (tile group, channel group): blocks b and b + 8 share an XCD (round-robin dispatch); the nbn channel
-    // groups of one tile group are neighbours in one XCD's stream, so its V chunks are fetched into that L2 once
+    // block -> (tile group mb, channel group nb).  Blocks b and b + 8 share an XCD (round-robin dispatch) and with it
+    // a 4 MB L2: each XCD works on as few channel groups as possible, so that its slice of U (36 x cin x 64 floats, read
+    // by every block of the XCD once per tile group) stays in that L2 and only V streams through it (speed only)
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int nb = idx % a.nbn;
-    const int mb = (idx / a.nbn) * 8 + xcd;
+    int nb, mb;
+    if (a.nbn % 8 == 0) {
+        const int r = a.nbn >> 3;
+        nb = xcd * r + idx % r; mb = idx / r;
+    } else if (8 % a.nbn == 0) {
+        const int per = 8 / a.nbn;
+        nb = xcd % a.nbn; mb = xcd / a.nbn + per * idx;
+    } else {
+        nb = idx % a.nbn; mb = (idx / a.nbn) * 8 + xcd;
+    }
     if (mb >= a.mbn) return;
     const int nkc = a.nkc;
-    unsigned long long st0 = 0, st1 = 0, st2 = 0;      // FFR_WF_TRACE (diagnostics): shader-clock stamps of the phases
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, se[4] = {0, 0, 0, 0};      // FFR_WF_TRACE (diagnostics): shader-clock stamps of the phases
     if (a.trace) st0 = __builtin_amdgcn_s_memtime();
-
-    float* const ring = smem + wave * WF_RING;
-    const float* vsrc = a.Vc + ((size_t)mb * nkc * 36 + 9 * wave) * 256 + lane * 4;
-    const float* usrc = a.Uc + ((size_t)nb * nkc * 36 + 9 * wave) * 512 + lane * 4;
-    const int rowl = lane & 31;
-    const int po = (2 * rowl + ((lane >> 5) ^ ((rowl >> 3) & 1))) * 4;     // this lane's piece, in floats
-
-    // 18 accumulator tiles = 288 registers, but a wave addresses 256 AGPRs + 256 VGPRs and hipcc keeps every builtin
-    // MFMA accumulator in AGPRs (a 17th tile is copied in and out around each of its MFMAs, with the full MFMA
-    // latency exposed): xi 0..7 of the wave use the builtin (16 tiles, all 256 AGPRs), xi 8 the VGPR form of the same
-    // instruction through inline asm (accv, 32 VGPRs)
-    f32x16 acc[8][2], accv[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            accv[nt][r] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j][nt][r] = 0.f;
-        }
-
-    auto dma = [&](int j, int part) {       // part 0: V piece, 1/2: the two halves of U; sources advance by one K chunk
-        float* slot = ring + j * WF_SLOT;
-        if (part == 0) __builtin_amdgcn_global_load_lds(GLB_PTR(vsrc + j * 256), LDS_PTR(slot), 16, 0, 0);
-        else if (part == 1) __builtin_amdgcn_global_load_lds(GLB_PTR(usrc + j * 512), LDS_PTR(slot + 256), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds(GLB_PTR(usrc + j * 512 + 256), LDS_PTR(slot + 512), 16, 0, 0);
-    };
-    f32x4 af[2], bf[2][2];
-    auto read_frag = [&](int buf, int j, int part) {
-        const float* slot = ring + j * WF_SLOT + po;
-        if (part == 0) af[buf] = *reinterpret_cast<const f32x4*>(slot);
-        else bf[buf][part - 1] = *reinterpret_cast<const f32x4*>(slot + 256 * part);
-    };
-#define FFR_PIN __builtin_amdgcn_sched_barrier(0)
-    // ---- prologue: K chunk 0 of all 9 xi in flight, fragments of xi 0 in registers ----
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        dma(j, 0); dma(j, 1); dma(j, 2);
-    }
-    vsrc += 36 * 256;
-    usrc += 36 * 512;
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    read_frag(0, 0, 0); read_frag(0, 0, 1); read_frag(0, 0, 2);
-    FFR_PIN;
-    if (a.trace) st1 = __builtin_amdgcn_s_memtime();
-
-    // one K chunk: 9 steps (xi) of 8 MFMAs.  LAST: nothing is fetched any more.
-    auto chunk = [&]<bool LAST>() {
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int cur = j & 1, nxt = cur ^ 1;
-            const int jn = (j + 1) % 9;            // next step's slot (next chunk's xi 0 after xi 8)
-            const bool has_next = !(LAST && j == 8);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int e = g >> 1, nt = g & 1;
-                if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][e], bf[cur][nt][e], acc[j][nt], 0, 0, 0);
-                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(af[cur][e]), "v"(bf[cur][nt][e]));
-                // fillers, one per MFMA gap: slot j is free once its fragments are in registers (they are: the first
-                // MFMA consumed them), so the next chunk's xi j goes into it; then the next step's fragments
-                if (!LAST && g < 3) dma(j, g);
-                if (has_next && g == 3) {
-                    // the data of step s+1 was issued 9 steps ago; 8 steps x 3 loads were issued since (fewer at the tail)
-                    wait_vmcnt(LAST ? 3 * (7 - j) : 24);
-                }
-                if (has_next && g >= 4 && g < 7) read_frag(nxt, jn, g - 4);
-                FFR_PIN;
-            }
-        }
-        // 9 steps: the fragments of the next chunk's xi 0 sit in buffer 1, step 0 reads buffer 0
-        if (!LAST) { af[0] = af[1]; bf[0][0] = bf[1][0]; bf[0][1] = bf[1][1]; }
-    };
-#pragma unroll 1
-    for (int kc = 0; kc + 1 < nkc; ++kc) {
-        chunk.template operator()<false>();
-        vsrc += 36 * 256;
-        usrc += 36 * 512;
-    }
-    chunk.template operator()<true>();
-#undef FFR_PIN
-    if (a.trace) st2 = __builtin_amdgcn_s_memtime();
-
-    // ---- epilogue ----------------------------------------------------------------------------------------
-    // One wave per SIMD: this phase is bound by instruction issue (~4.5 cycles each), so it is written for few
-    // instructions: two passes (one per 32-channel half), whole accumulator tiles per pass, 8-byte LDS reads, packed
-    // fp32 math on channel pairs, per-tile geometry from a small LDS table, one 8-byte store per pixel and lane.
-    // the inline-asm MFMAs are invisible to hipcc's hazard recognizer: their results must not be read for 18 cycles
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    __syncthreads();          // every wave is done with its ring
+    // epilogue tables (their LDS is never aliased; the epilogue's first barrier publishes them)
     const int tid = threadIdx.x;
     const int n0 = nb * 64;
-    const int hsel = lane >> 5;
     float* const s_bias = smem + WF_EPI_FLOATS;                       // [9][64] border-class biases of this channel group
     int* const s_tile = reinterpret_cast<int*>(s_bias + 9 * 64);     // [32][4]: origin pixel, valid rows | cols << 8, border rows, border cols
     for (int i = tid; i < (a.border_bias ? 9 : 1) * 64; i += 256) s_bias[i] = a.bias[(size_t)(i >> 6) * a.cout_pad + n0 + (i & 63)];
@@ -274,8 +201,80 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         }
         s_tile[tid * 4 + 0] = pix0; s_tile[tid * 4 + 1] = vrc; s_tile[tid * 4 + 2] = br; s_tile[tid * 4 + 3] = bc;
     }
-    const int cp = lane & 15;                       // channel pair of this lane within the 32-channel half
-    const bool vec2 = ((a.out_pitch | a.out_coff | a.res_pitch | a.cout_pad) & 1) == 0;
+
+    // operand streams of this wave: one 16-byte fragment per lane, xi and K chunk (lane-linear in memory)
+    const float* vp = a.Vc + ((size_t)mb * nkc * 36 + 9 * wave) * 256 + lane * 4;
+    const float* up = a.Uc + ((size_t)nb * nkc * 36 + 9 * wave) * 512 + lane * 4;
+    const int rowl = lane & 31;
+
+    // 18 accumulator tiles = 288 registers, but a wave addresses 256 AGPRs + 256 VGPRs and hipcc keeps every builtin
+    // MFMA accumulator in AGPRs (a 17th tile is copied in and out around each of its MFMAs, with the full MFMA
+    // latency exposed): xi 0..7 of the wave use the builtin (16 tiles, all 256 AGPRs), xi 8 the VGPR form of the same
+    // instruction through inline asm (accv, 32 VGPRs)
+    f32x16 acc[8][2], accv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accv[nt][r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j][nt][r] = 0.f;
+        }
+
+    // fragment registers: slot j holds (V, U lo, U hi) of xi j for the K chunk that consumes it next
+    f32x4 fv[9], fu[9][2];
+    auto load = [&](int j, int part, const float* v, const float* u) {
+        if (part == 0) fv[j] = *reinterpret_cast<const f32x4*>(v + j * 256);
+        else fu[j][part - 1] = *reinterpret_cast<const f32x4*>(u + j * 512 + (part - 1) * 256);
+    };
+#define FFR_PIN __builtin_amdgcn_sched_barrier(0)
+    // ---- prologue: xi 0..7 of K chunk 0 in flight (xi 8 follows in step 0) ----
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        load(j, 0, vp, up); load(j, 1, vp, up); load(j, 2, vp, up);
+    }
+    FFR_PIN;
+    if (a.trace) st1 = __builtin_amdgcn_s_memtime();
+
+    // one K chunk: 9 steps (xi) of 8 MFMAs; every step reloads the slot the previous step consumed, 8 steps ahead of
+    // its next use.  vp/up point at the chunk being multiplied.  LAST: no chunk follows.
+    auto chunk = [&]<bool LAST>() {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const f32x4 av = fv[j], b0 = fu[j][0], b1 = fu[j][1];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int e = g >> 1, nt = g & 1;
+                if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
+                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
+                // fillers, one per MFMA gap
+                if (g >= 1 && g < 4) {
+                    if (j == 0) load(8, g - 1, vp, up);                                        // xi 8 of this chunk
+                    else if (!LAST) load(j - 1, g - 1, vp + 36 * 256, up + 36 * 512);          // xi j-1 of the next chunk
+                }
+                FFR_PIN;
+            }
+        }
+    };
+#pragma unroll 1
+    for (int kc = 0; kc + 1 < nkc; ++kc) {
+        chunk.template operator()<false>();
+        vp += 36 * 256;
+        up += 36 * 512;
+    }
+    chunk.template operator()<true>();
+#undef FFR_PIN
+    if (a.trace) st2 = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue ----------------------------------------------------------------------------------------
+    // One wave per SIMD: this phase is bound by instruction issue (~4.5 cycles each), so it is written for few
+    // instructions: two passes (one per 32-channel half), whole accumulator tiles per pass, 8-byte LDS reads, packed
+    // fp32 math on channel pairs, per-tile geometry from a small LDS table, one 8-byte store per pixel and lane.
+    // the inline-asm MFMAs are invisible to hipcc's hazard recognizer: their results must not be read for 18 cycles
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const int hsel = lane >> 5;
+    const int cq = lane & 7;                        // channel quad of this lane within the 32-channel half
+    const bool vec4 = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         // E[xi][tile][co]: the 32-channel half nt of all 32 tiles
@@ -285,37 +284,37 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
             for (int r = 0; r < 16; ++r)
                 smem[((9 * wave + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + rowl] = j < 8 ? acc[j][nt][r] : accv[nt][r];
         __syncthreads();
-#pragma unroll 1
-        for (int q = 0; q < 2; ++q) {
-            const int tl = (lane >> 4) + 4 * wave + 16 * q;
-            const int vrc = s_tile[tl * 4 + 1];
-            if (vrc == 0) continue;                                     // tile beyond T
+        if (a.trace) se[2 * nt] = __builtin_amdgcn_s_memtime();
+        // one (tile, 4 channels) per thread: a wave-instruction reads / stores 8 tiles x 128 bytes
+        const int tl = (lane >> 3) + 8 * wave;
+        const int vrc = s_tile[tl * 4 + 1];
+        if (vrc != 0) {                                                 // else: tile beyond T
             const int pix0 = s_tile[tl * 4 + 0];
             const int vr = vrc & 0xff, vc = vrc >> 8;
-            const f32x2* e = reinterpret_cast<const f32x2*>(smem + tl * 32 + 2 * cp);
-            f32x2 y[4][4];
+            const f32x4* e = reinterpret_cast<const f32x4*>(smem + tl * 32 + 4 * cq);
+            f32x4 y[4][4];
             {
-                f32x2 tmp[4][6];
+                f32x4 tmp[4][6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    f32x2 mc[6], yc[4];
+                    f32x4 mc[6], yc[4];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) mc[i] = e[(i * 6 + j) * 512];
-                    at6p(mc, yc);
+                    for (int i = 0; i < 6; ++i) mc[i] = e[(i * 6 + j) * 256];
+                    at6q(mc, yc);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) tmp[i][j] = yc[i];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) at6p(tmp[i], y[i]);
+                for (int i = 0; i < 4; ++i) at6q(tmp[i], y[i]);
             }
-            const int cl = nt * 32 + 2 * cp;            // channel within the 64-channel group
+            const int cl = nt * 32 + 4 * cq;            // channel within the 64-channel group
             const int cg = n0 + cl;
-            f32x2 slope = {1.f, 1.f};
-            if (a.slope) slope = *reinterpret_cast<const f32x2*>(a.slope + cg);
+            f32x4 slope = {1.f, 1.f, 1.f, 1.f};
+            if (a.slope) slope = *reinterpret_cast<const f32x4*>(a.slope + cg);
             // bias per pixel: one value, or one of 9 border classes
-            f32x2 bs[4][4];
+            f32x4 bs[4][4];
             if (!a.border_bias) {
-                const f32x2 b0 = *reinterpret_cast<const f32x2*>(s_bias + cl);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_bias + cl);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -331,38 +330,47 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) bs[i][jj] = *reinterpret_cast<const f32x2*>(s_bias + rc[i] + cc[jj] + cl);
+                    for (int jj = 0; jj < 4; ++jj) bs[i][jj] = *reinterpret_cast<const f32x4*>(s_bias + rc[i] + cc[jj] + cl);
             }
-            const bool ok0 = cg < a.cout_store, ok1 = cg + 1 < a.cout_store;
-            f32x2 psum = {0.f, 0.f};
-            if (vec2 && ok1) {
+            f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+            if (vec4 && cg + 3 < a.cout_store) {
+                // Branch-free stores: pixel (i, jj) of a tile that hangs over the map's edge is redirected to the tile's
+                // last valid row / column, and the pixels are stored in DESCENDING order: the stray value lands first,
+                // the right one (same lane, same address, program order) overwrites it.
+                int ro[4], co[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ro[i] = (i < vr ? i : vr - 1) * a.W;
+                    co[i] = i < vc ? i : vc - 1;
+                }
                 float* const ob = a.out + (size_t)pix0 * a.out_pitch + a.out_coff + cg;
                 const float* const rb = a.resid ? a.resid + (size_t)pix0 * a.res_pitch + cg : nullptr;
-                f32x2 rs[4][4];
+                f32x4 rs[4][4];
                 if (rb) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const bool ok = i < vr && jj < vc;      // out-of-map pixels read the tile's origin pixel
-                            rs[i][jj] = *reinterpret_cast<const f32x2*>(rb + (ok ? (i * a.W + jj) * a.res_pitch : 0));
-                        }
+                        for (int jj = 0; jj < 4; ++jj) rs[i][jj] = *reinterpret_cast<const f32x4*>(rb + (ro[i] + co[jj]) * a.res_pitch);
                 }
+                float mr[4], mc[4];          // 1 for pixels inside the map (SE tile sums)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) { mr[i] = i < vr ? 1.f : 0.f; mc[i] = i < vc ? 1.f : 0.f; }
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        f32x2 v = y[i][jj] + bs[i][jj];
-                        v[0] = v[0] >= 0.f ? v[0] : v[0] * slope[0];
-                        v[1] = v[1] >= 0.f ? v[1] : v[1] * slope[1];
+                for (int i = 3; i >= 0; --i)
+#pragma unroll
+                    for (int jj = 3; jj >= 0; --jj) {
+                        f32x4 v = y[i][jj] + bs[i][jj];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f) + slope[c] * fminf(v[c], 0.f);     // PReLU without VCC
                         if (rb) v += rs[i][jj];
-                        if (a.flags & 1) { v[0] = 1.0f / (1.0f + __expf(-v[0])); v[1] = 1.0f / (1.0f + __expf(-v[1])); }
-                        if (i < vr && jj < vc) {
-                            *reinterpret_cast<f32x2*>(ob + (i * a.W + jj) * a.out_pitch) = v;
-                            psum += v;
+                        if (a.flags & 1) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = 1.0f / (1.0f + __expf(-v[c]));
                         }
+                        *reinterpret_cast<f32x4*>(ob + (ro[i] + co[jj]) * a.out_pitch) = v;
+                        if (a.tile_sums) psum += v * (mr[i] * mc[jj]);
                     }
-            } else if (ok0) {            // odd pitches / channel counts: scalar stores
+            } else {            // odd pitches / channel counts: scalar stores
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -370,10 +378,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                         if (!(i < vr && jj < vc)) continue;
                         const size_t m = (size_t)pix0 + i * a.W + jj;
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) {
+                        for (int c = 0; c < 4; ++c) {
                             if (cg + c >= a.cout_store) continue;
                             float v = y[i][jj][c] + bs[i][jj][c];
-                            v = v >= 0.f ? v : v * slope[c];
+                            v = fmaxf(v, 0.f) + slope[c] * fminf(v, 0.f);
                             if (a.resid) v += a.resid[m * a.res_pitch + cg + c];
                             if (a.flags & 1) v = 1.0f / (1.0f + __expf(-v));
                             a.out[m * a.out_pitch + a.out_coff + cg + c] = v;
@@ -383,14 +391,16 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
             }
             if (a.tile_sums) {
                 const long long t = (long long)mb * 32 + tl;
-                *reinterpret_cast<f32x2*>(a.tile_sums + (size_t)t * a.cout_pad + cg) = psum;
+                *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)t * a.cout_pad + cg) = psum;
             }
         }
+        if (a.trace) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
     if (a.trace && lane == 0) {
-        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 6;
+        unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 10;
         tr[0] = st0; tr[1] = st1; tr[2] = st2; tr[3] = __builtin_amdgcn_s_memtime();
+        tr[6] = se[0]; tr[7] = se[1]; tr[8] = se[2]; tr[9] = se[3];
         tr[4] = __builtin_amdgcn_s_memrealtime();
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -402,9 +412,15 @@ hipError_t wino_fused_init() {
     return hipFuncSetAttribute((const void*)k_wino_fused, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
 }
 
+static int wf_grid(int mbn, int nbn) {      // inverse of the block decoding in k_wino_fused
+    if (nbn % 8 == 0) return mbn * nbn;
+    if (8 % nbn == 0) { const int per = 8 / nbn; return 8 * ((mbn + per - 1) / per); }
+    return (mbn + 7) / 8 * 8 * nbn;
+}
+
 int wino_fused_blocks(const WinoFusedArgs& a) {
     const long long T = (long long)a.N * ((a.H + 3) / 4) * ((a.W + 3) / 4);
-    return (int)(((T + 31) / 32 + 7) / 8) * 8 * (a.cout_pad / 64);
+    return wf_grid((int)((T + 31) / 32), a.cout_pad / 64);
 }
 
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
@@ -413,8 +429,7 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
     a.T = (long long)a.N * a.th * a.tw;
     a.mbn = (int)((a.T + 31) / 32);
     a.nbn = a.cout_pad / 64;
-    const int groups = (a.mbn + 7) / 8;
-    hipLaunchKernelGGL(k_wino_fused, dim3(groups * a.nbn * 8), dim3(256), WF_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(k_wino_fused, dim3(wf_grid(a.mbn, a.nbn)), dim3(256), WF_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
