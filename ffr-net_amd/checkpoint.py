@@ -44,7 +44,10 @@ def load_recnet_checkpoint(recnet, file_path):
 
 
 def save_recnet_checkpoint(recnet, file_path, optimizer_state=None, extra_info=None):
-    """Trainer.save_model layout."""
+    """Trainer.save_model layout.  `recnet`: an nn.Module (pass the torch optimizer's state_dict()) or a NativeTrainer
+    (its Adam step count and moment buffers are saved unless optimizer_state is given)."""
+    if optimizer_state is None and hasattr(recnet, 'optimizer_state_dict'):
+        optimizer_state = recnet.optimizer_state_dict()
     d = {'RecNet': recnet.state_dict(), 'optimizer': optimizer_state if optimizer_state is not None else {}}
     if extra_info is not None:
         d.update(extra_info)

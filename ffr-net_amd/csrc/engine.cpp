@@ -339,7 +339,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
                 return FFR_OK;
             }
-            Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes, fexec);
+            Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec);
             HIPCK(h, launch_wino_fused(f, st));
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
             return FFR_OK;
@@ -396,8 +396,6 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     }
                     GemmStreamArgs g{};
                     g.A = c.winoV; g.W = L.wu; g.C = c.winoM; g.M = (int)Ts; g.K = L.cin_pad; g.Npad = L.cout_pad; g.nbatch = 36;
-                    static const int ablate = getenv("FFR_GS_ABLATE") ? atoi(getenv("FFR_GS_ABLATE")) : 0;
-                    g.ablate = ablate;
                     int bm, bn;
                     igemm_tile_shape(gtile, &bm, &bn);
                     const double fexec = 2.0 * 36.0 * (double)((Ts + bm - 1) / bm) * bm * (double)L.cout_pad * L.cin_pad;
@@ -483,7 +481,7 @@ Work layout(char* base, int N, int H, int W) {
 int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
     const size_t need = layout(nullptr, N, H, W).total;
     if (need > h->arena_bytes) {
-        if (h->arena) { hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; }
+        if (h->arena) { hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; ++h->generation; }
         void* p = nullptr;
         if (hipMalloc(&p, need) != hipSuccess)
             return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu workspace bytes failed", need);
@@ -493,7 +491,7 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
     }
     const size_t need_t = (size_t)N * H * W / 64 + 4096;
     if (need_t > h->tickets_cap) {
-        if (h->tickets) { hipDeviceSynchronize(); hipFree(h->tickets); h->tickets = nullptr; h->tickets_cap = 0; }
+        if (h->tickets) { hipDeviceSynchronize(); hipFree(h->tickets); h->tickets = nullptr; h->tickets_cap = 0; ++h->generation; }
         void* p = nullptr;
         if (hipMalloc(&p, need_t * sizeof(int)) != hipSuccess) return fail(h, FFR_ERR_NOMEM, "hipMalloc of the ticket array failed");
         if (hipMemset(p, 0, need_t * sizeof(int)) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipMemset failed");
@@ -682,7 +680,8 @@ int check_fwd(ffr_handle* h, bool need_enc, bool need_rec, int N) {
     if (N <= 0) return fail(h, FFR_ERR_ARG, "N must be positive");
     if (need_enc && !h->enc_loaded) return fail(h, FFR_ERR_STATE, "encoder weights are not loaded");
     if (need_rec && !h->rec_loaded) return fail(h, FFR_ERR_STATE, "recnet weights are not loaded");
-    if (hipSetDevice(h->device) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
     return FFR_OK;
 }
 
@@ -702,7 +701,8 @@ int ffr_create(ffr_handle** out, int device) {
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(nullptr, FFR_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= count) return fail(nullptr, FFR_ERR_ARG, "device %d out of range (%d devices)", device, count);
-    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FFR_ERR_HIP, "hipSetDevice(%d) failed", device);
+    DeviceScope scope(device);
+    if (!scope.ok) return fail(nullptr, FFR_ERR_HIP, "hipSetDevice(%d) failed", device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, FFR_ERR_HIP, "hipGetDeviceProperties failed");
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -727,7 +727,7 @@ int ffr_create(ffr_handle** out, int device) {
 
 void ffr_destroy(ffr_handle* h) {
     if (!h) return;
-    hipSetDevice(h->device);
+    FFR_DEVICE_SCOPE(h);
     hipDeviceSynchronize();
     train_free(h);
     free_list(h->enc_allocs);
@@ -742,9 +742,10 @@ void ffr_destroy(ffr_handle* h) {
 
 int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
     if (!h || !t || n <= 0) return fail(h, FFR_ERR_ARG, "ffr_load_encoder: bad arguments");
-    RC(check_fwd(h, false, false, 1));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, 1));
     hipDeviceSynchronize();
     free_list(h->enc_allocs);
+    ++h->generation;
     h->enc_loaded = false;
     SD sd; sd.h = h;
     for (int i = 0; i < n; ++i) if (t[i].name) sd.m[t[i].name] = &t[i];
@@ -831,9 +832,10 @@ int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
 
 int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n) {
     if (!h || !t || n <= 0) return fail(h, FFR_ERR_ARG, "ffr_load_recnet: bad arguments");
-    RC(check_fwd(h, false, false, 1));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, 1));
     hipDeviceSynchronize();
     free_list(h->rec_allocs);
+    ++h->generation;
     h->rec_loaded = false;
     SD sd; sd.h = h;
     for (int i = 0; i < n; ++i) if (t[i].name) sd.m[t[i].name] = &t[i];
@@ -939,13 +941,13 @@ size_t ffr_workspace_bytes(const ffr_handle* h, int N, int H, int W) {
 }
 
 int ffr_reserve(ffr_handle* h, int N, int H, int W) {
-    RC(check_fwd(h, false, false, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, N));
     Work w;
     return ensure_arena(h, N, H, W, &w);
 }
 
 int ffr_encoder_forward(ffr_handle* h, const float* x, int N, int H, int W, float* featmap_nchw, float* f, void* stream) {
-    RC(check_fwd(h, true, false, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, true, false, N));
     if (!x) return fail(h, FFR_ERR_ARG, "x is null");
     if (H < 32 || W < 32 || (H & 15) || (W & 15)) return fail(h, FFR_ERR_ARG, "H and W must be multiples of 16, >= 32");
     if (f && (H != 112 || W != 112)) return fail(h, FFR_ERR_UNSUPPORTED, "f needs a 112x112 input (Linear(512*7*7,512))");
@@ -961,7 +963,7 @@ int ffr_encoder_forward(ffr_handle* h, const float* x, int N, int H, int W, floa
 }
 
 int ffr_recnet_forward(ffr_handle* h, const float* featmap_nchw, int N, float* f_new, float* feat_new_nchw, void* stream) {
-    RC(check_fwd(h, false, true, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, true, N));
     if (!featmap_nchw) return fail(h, FFR_ERR_ARG, "featmap is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;
@@ -979,7 +981,7 @@ int ffr_recnet_forward(ffr_handle* h, const float* featmap_nchw, int N, float* f
 }
 
 int ffr_embed(ffr_handle* h, const float* x, int N, float* f_new, float* f, void* stream) {
-    RC(check_fwd(h, true, true, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, true, true, N));
     if (!x || !f_new) return fail(h, FFR_ERR_ARG, "x / f_new is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;
@@ -990,7 +992,7 @@ int ffr_embed(ffr_handle* h, const float* x, int N, float* f_new, float* f, void
 
 int ffr_embed_u8(ffr_handle* h, const uint8_t* img_hwc_rgb, const uint8_t* flip, int N, float* f_new, float* f,
                  void* stream) {
-    RC(check_fwd(h, true, true, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, true, true, N));
     if (!img_hwc_rgb || !f_new) return fail(h, FFR_ERR_ARG, "img / f_new is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;
@@ -1001,7 +1003,7 @@ int ffr_embed_u8(ffr_handle* h, const uint8_t* img_hwc_rgb, const uint8_t* flip,
 }
 
 int ffr_cosine_scores(ffr_handle* h, const float* a, const float* b, int n, int dim, float* score, void* stream) {
-    RC(check_fwd(h, false, false, n));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, n));
     if (!a || !b || !score || dim <= 0) return fail(h, FFR_ERR_ARG, "ffr_cosine_scores: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     Scope s(h, st, FFR_KC_SCORE, 6.0 * n * dim, 8.0 * n * dim);
@@ -1011,7 +1013,7 @@ int ffr_cosine_scores(ffr_handle* h, const float* a, const float* b, int n, int 
 
 int ffr_lfw_fold_accuracy(ffr_handle* h, const float* score, const int32_t* label, int n, int n_folds, double* best_thr,
                           double* test_acc, void* stream) {
-    RC(check_fwd(h, false, false, n));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, n));
     if (!score || !label || !best_thr || !test_acc || n_folds < 1 || n_folds > 32 || n < n_folds)
         return fail(h, FFR_ERR_ARG, "ffr_lfw_fold_accuracy: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -1019,6 +1021,38 @@ int ffr_lfw_fold_accuracy(ffr_handle* h, const float* score, const int32_t* labe
     RC(ensure_arena(h, 8, 112, 112, &w));
     Scope s(h, st, FFR_KC_SCORE, 400.0 * n, 8.0 * 400 * n);
     HIPCK(h, launch_fold_protocol(score, (const int*)label, n, n_folds, (int*)w.partial, best_thr, test_acc, st));
+    return FFR_OK;
+}
+
+unsigned long long ffr_generation(const ffr_handle* h) { return h ? h->generation : 0; }
+
+int ffr_probe_mfma_peak(ffr_handle* h, int iters, double* tflops, double* clock_ghz, void* stream) {
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, 1));
+    if (iters <= 0 || !tflops) return fail(h, FFR_ERR_ARG, "ffr_probe_mfma_peak: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = 256 * 2;                    // 2 blocks of 4 waves per CU
+    unsigned long long* stamps = nullptr;
+    float* sink = nullptr;
+    HIPCK(h, hipMalloc((void**)&stamps, (size_t)blocks * 4 * sizeof(unsigned long long)));
+    HIPCK(h, hipMalloc((void**)&sink, (size_t)blocks * 256 * sizeof(float)));
+    hipEvent_t e0, e1;
+    HIPCK(h, hipEventCreate(&e0)); HIPCK(h, hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep) HIPCK(h, launch_mfma_probe(iters, blocks, stamps, sink, st));   // warm the clock
+    HIPCK(h, hipEventRecord(e0, st));
+    HIPCK(h, launch_mfma_probe(iters, blocks, stamps, sink, st));
+    HIPCK(h, hipEventRecord(e1, st));
+    HIPCK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCK(h, hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> sv((size_t)blocks * 4);
+    HIPCK(h, hipMemcpy(sv.data(), stamps, sv.size() * 8, hipMemcpyDeviceToHost));
+    double ghz = 0;
+    for (int b = 0; b < blocks; ++b) ghz += (double)(sv[b * 4 + 1] - sv[b * 4 + 0]) / ((double)(sv[b * 4 + 3] - sv[b * 4 + 2]) * 10.0);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(stamps); hipFree(sink);
+    // 4 waves x 16 MFMAs of 32x32x2 (4096 FLOP each) per iteration and block
+    *tflops = (double)blocks * 4.0 * iters * 16.0 * 4096.0 / ((double)ms * 1e-3) / 1e12;
+    if (clock_ghz) *clock_ghz = ghz / blocks;
     return FFR_OK;
 }
 
@@ -1049,7 +1083,7 @@ int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
 
 int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream) {
     if (!d) return fail(h, FFR_ERR_ARG, "desc is null");
-    RC(check_fwd(h, false, false, d->N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, d->N));
     if (!d->x || !d->w || !d->bias || !d->out) return fail(h, FFR_ERR_ARG, "ffr_op_conv: null tensor");
     if (d->cin_pad % 32 || d->cout_pad % 64 || d->cin_pad <= 0) return fail(h, FFR_ERR_ARG, "ffr_op_conv: bad padding");
     Work w;
@@ -1068,7 +1102,7 @@ int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream) {
 int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, const float* w_host,
                    const float* bias_host, const float* slope_host, int cout, int pad_mode, int use_wino,
                    const float* resid, float* out, void* stream) {
-    RC(check_fwd(h, false, false, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, N));
     if (!x || !w_host || !bias_host || !out || cin % 32 || cout % 4 || cin <= 0 || cout <= 0)
         return fail(h, FFR_ERR_ARG, "ffr_op_conv3x3: bad arguments (cin %% 32, cout %% 4)");
     hipStream_t st = (hipStream_t)stream;
@@ -1098,7 +1132,7 @@ int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, 
 }
 
 int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, int n_blocks, float* out, void* stream) {
-    RC(check_fwd(h, true, false, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, true, false, N));
     if (!x || !out || n_blocks < 0 || n_blocks > 24) return fail(h, FFR_ERR_ARG, "ffr_encoder_trunk_nhwc: bad arguments");
     if (H < 32 || W < 32 || (H & 15) || (W & 15)) return fail(h, FFR_ERR_ARG, "H and W must be multiples of 16, >= 32");
     hipStream_t st = (hipStream_t)stream;
@@ -1112,7 +1146,7 @@ int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, i
 
 int ffr_recnet_debug(ffr_handle* h, const float* featmap_nchw, int N, float* ss_space, float* M_space, float* feat_space,
                      float* feat_channel_raw, float* feat_channel, void* stream) {
-    RC(check_fwd(h, false, true, N));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, true, N));
     if (!featmap_nchw) return fail(h, FFR_ERR_ARG, "featmap is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;

@@ -72,6 +72,9 @@ struct ffr_handle {
     std::vector<hipEvent_t> ev_pool;
     // RecNet training state (train.cpp), or null
     ffr_eng::TrainState* train = nullptr;
+    // bumped whenever device memory a caller may have captured (hipGraph) is released: workspace regrowth, weight
+    // reload, ffr_train_init
+    unsigned long long generation = 1;
 };
 
 namespace ffr_eng {
@@ -92,6 +95,20 @@ int fail(ffr_handle* h, int code, const char* fmt, ...);
     } while (0)
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Every C entry point runs on its handle's device and leaves the calling thread's current device as it found it
+// (a process may hold several handles / torch may have another device current).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit DeviceScope(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; switched = ok && prev >= 0; }
+    }
+    ~DeviceScope() { if (switched) hipSetDevice(prev); }
+};
+#define FFR_DEVICE_SCOPE(h) ffr_eng::DeviceScope _dev_scope((h) ? (h)->device : -1)
 
 // ---- profiling scope: hipEvents on the launch stream around one launch -----------------
 struct Scope {

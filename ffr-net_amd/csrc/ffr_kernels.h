@@ -43,7 +43,6 @@ struct GemmStreamArgs {
     const float* A; const float* W; float* C;
     int M, K, Npad, nbatch;
     int mtiles, ntiles;      // filled by the launcher
-    int ablate;              // timing experiments only (tools/): bit0 = skip the stores
 };
 hipError_t gemm_stream_init();
 hipError_t launch_gemm_stream(GemmStreamArgs a, int tile, int nblocks, hipStream_t stream);
@@ -86,6 +85,11 @@ int wino_fused_blocks(const WinoFusedArgs& a);
 hipError_t wino_fused_init();
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream);
 inline size_t wino_chunked_floats(long long T, int cin_pad) { return (size_t)((T + 31) / 32) * 32 * 36 * cin_pad; }
+
+// ---- measurement: what the fp32 matrix cores deliver on THIS device (probe.hip) ------------------------
+// `blocks` x 256 threads, each wave issues iters x 16 independent-accumulator v_mfma_f32_32x32x2_f32 on random
+// register operands; stamps[block*4 + {0,1,2,3}] = s_memtime begin/end, s_memrealtime begin/end of wave 0
+hipError_t launch_mfma_probe(int iters, int blocks, unsigned long long* stamps, float* sink, hipStream_t stream);
 
 // ---- trunk elementwise (elementwise.hip) -------------------------------------------
 // stem: x_nchw[N,3,H,W] -> out[N,H,W,64] = PReLU(conv3x3(x)*bnscale + bias); w [27][64] folded

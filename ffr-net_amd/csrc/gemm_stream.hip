@@ -166,8 +166,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : 3)) void k_gemm_st
                 if (mrow_cur + mlr < a.M) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (a.ablate & 1) asm volatile("" :: "v"(acc[i][j][r]));
-                        else orow_cur[(size_t)mlr * a.Npad + j * 32] = acc[i][j][r];
+                        orow_cur[(size_t)mlr * a.Npad + j * 32] = acc[i][j][r];
                     }
                 }
             }

@@ -403,7 +403,8 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
 int get_train(ffr_handle* h, TrainState** t) {
     if (!h) return fail(nullptr, FFR_ERR_ARG, "null handle");
     if (!h->train) return fail(h, FFR_ERR_STATE, "ffr_train_init has not been called");
-    if (hipSetDevice(h->device) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
     *t = h->train;
     return FFR_OK;
 }
@@ -644,7 +645,7 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
                            const float* gamma_host, const float* beta_host, const float* slope_host,
                            const float* da_nhwc, float* out_nhwc, float* dx_nhwc, float* dw_packed, float* dvec,
                            float* stats, void* stream) {
-    RC(check_fwd(h, false, false, 1));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, 1));
     if (!x_nhwc || !w_host || !gamma_host || !beta_host || !slope_host || !da_nhwc || !out_nhwc || G <= 0 || N <= 0)
         return fail(h, FFR_ERR_ARG, "ffr_op_convlayer_train: bad arguments");
     hipStream_t st = (hipStream_t)stream;
@@ -695,8 +696,9 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
 
 int ffr_train_init(ffr_handle* h, const ffr_tensor_desc* td, int n) {
     if (!h || !td || n <= 0) return fail(h, FFR_ERR_ARG, "ffr_train_init: bad arguments");
-    RC(check_fwd(h, false, false, 1));
+    FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, 1));
     train_free(h);
+    ++h->generation;
     TrainState* t = new TrainState();
     h->train = t;
     SD sd; sd.h = h;
@@ -795,7 +797,7 @@ int ffr_train_init(ffr_handle* h, const ffr_tensor_desc* td, int n) {
 int ffr_train_info(ffr_handle* h, float** params, float** grads, size_t* n_flat, long long* num_batches_tracked,
                    int* adam_step) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (params) *params = t->P;
     if (grads) *grads = t->Gr;
     if (n_flat) *n_flat = t->n_flat;
@@ -806,7 +808,7 @@ int ffr_train_info(ffr_handle* h, float** params, float** grads, size_t* n_flat,
 
 int ffr_train_get(ffr_handle* h, int which, const char* key, float* host_out, size_t n) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (!key || !host_out) return fail(h, FFR_ERR_ARG, "ffr_train_get: null argument");
     HIPCK(h, hipDeviceSynchronize());
     if (which == 4) {
@@ -830,7 +832,7 @@ int ffr_train_get(ffr_handle* h, int which, const char* key, float* host_out, si
 
 int ffr_train_set(ffr_handle* h, int which, const char* key, const float* host_in, size_t n) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (!key || !host_in) return fail(h, FFR_ERR_ARG, "ffr_train_set: null argument");
     HIPCK(h, hipDeviceSynchronize());
     auto it = t->seg_of.find(key);
@@ -847,7 +849,7 @@ int ffr_train_set(ffr_handle* h, int which, const char* key, const float* host_i
 
 int ffr_train_zero_grad(ffr_handle* h, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, (hipStream_t)stream));
     return FFR_OK;
 }
@@ -856,7 +858,7 @@ int ffr_train_forward(ffr_handle* h, int slot, const float* featmap_nchw, const 
                       float* f_new, float* pred_loss, float* pred_label, float* M_space, float* M_channel,
                       float* feat_space, float* feat_channel, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (slot < 0 || slot > 1 || !featmap_nchw || G <= 0 || N <= 0 || ((pred_loss || pred_label) && !label))
         return fail(h, FFR_ERR_ARG, "ffr_train_forward: bad arguments");
     if (N * 49 < 2) return fail(h, FFR_ERR_ARG, "ffr_train_forward: batch statistics need more than one value per channel");
@@ -884,7 +886,7 @@ int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const floa
                        const float* d_M_space, const float* d_M_channel, const float* d_feat_space,
                        const float* d_feat_channel, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (slot < 0 || slot > 1) return fail(h, FFR_ERR_ARG, "ffr_train_backward: bad slot");
     Ctx& c = t->ctx[slot];
     if (!c.valid) return fail(h, FFR_ERR_STATE, "ffr_train_backward: no forward recorded in slot %d", slot);
@@ -901,7 +903,7 @@ int ffr_train_backward(ffr_handle* h, int slot, const float* d_f_new, const floa
 int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, double eps, double weight_decay,
                         double clip_value, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     t->adam_step += 1;
     HIPCK(h, launch_adam(t->P, t->Gr, t->M1, t->M2, t->n_flat, lr, beta1, beta2, eps, weight_decay,
                          clip_value > 0.0 ? (float)clip_value : 3.0e38f, t->adam_step, (hipStream_t)stream));
@@ -912,7 +914,7 @@ int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, do
 // Test hook: copy a named intermediate of context `slot` (or of the backward scratch) to the host.
 int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_out, size_t n) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (slot < 0 || slot > 1 || !name || !host_out) return fail(h, FFR_ERR_ARG, "ffr_train_debug_copy: bad arguments");
     Ctx& c = t->ctx[slot];
     if (!c.mem) return fail(h, FFR_ERR_STATE, "no forward in slot %d", slot);
@@ -931,10 +933,15 @@ int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_
 
 int ffr_train_option(ffr_handle* h, const char* name, int value) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (!name) return fail(h, FFR_ERR_ARG, "ffr_train_option: null name");
     if (std::string(name) == "winograd") { t->sc.wino = value != 0; return FFR_OK; }
     if (std::string(name) == "fold_channel") { t->sc.fold = value != 0; return FFR_OK; }
+    if (std::string(name) == "adam_step") {      // resume: Adam's bias correction continues from the saved step count
+        if (value < 0) return fail(h, FFR_ERR_ARG, "ffr_train_option: adam_step must be >= 0");
+        t->adam_step = value;
+        return FFR_OK;
+    }
     return fail(h, FFR_ERR_KEY, "ffr_train_option: unknown option '%s'", name);
 }
 
@@ -942,7 +949,7 @@ int ffr_train_option(ffr_handle* h, const char* name, int value) {
 // device-to-device conversion of one entry: dir 0 = export (kernel layout -> torch layout), 1 = import
 static int train_convert(ffr_handle* h, int which, const char* key, float* dev, int dir, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (!key || !dev) return fail(h, FFR_ERR_ARG, "ffr_train_export/import: null argument");
     hipStream_t st = (hipStream_t)stream;
     if (which == 4) {
@@ -973,7 +980,7 @@ int ffr_train_import(ffr_handle* h, int which, const char* key, const float* dev
 
 int ffr_train_losses(ffr_handle* h, int slot, const float* f_enc, const double* loss_weight, float* out5, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (slot < 0 || slot > 1 || !f_enc || !loss_weight) return fail(h, FFR_ERR_ARG, "ffr_train_losses: bad arguments");
     Ctx& c = t->ctx[slot];
     if (!c.valid) return fail(h, FFR_ERR_STATE, "ffr_train_losses: no forward recorded in slot %d", slot);
@@ -988,7 +995,7 @@ int ffr_train_losses(ffr_handle* h, int slot, const float* f_enc, const double* 
 
 int ffr_train_backward_losses(ffr_handle* h, int slot, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (slot < 0 || slot > 1) return fail(h, FFR_ERR_ARG, "ffr_train_backward_losses: bad slot");
     Ctx& c = t->ctx[slot];
     if (!c.valid || !t->loss_grads_ready) return fail(h, FFR_ERR_STATE, "ffr_train_backward_losses: call ffr_train_forward and ffr_train_losses first");
@@ -1008,7 +1015,7 @@ int ffr_train_backward_losses(ffr_handle* h, int slot, void* stream) {
 int ffr_train_iteration(ffr_handle* h, const float* img_non, const float* img_ocl, const int32_t* label, int N,
                         const double* loss_weight, float* out5, void* stream) {
     TrainState* t;
-    RC(get_train(h, &t));
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     RC(check_fwd(h, true, false, N));
     if (!img_non || !img_ocl || !label || !loss_weight) return fail(h, FFR_ERR_ARG, "ffr_train_iteration: null argument");
     hipStream_t st = (hipStream_t)stream;

@@ -12,9 +12,10 @@ libffrnet_hip.so (hand-written gfx950 kernels) through ffrnet_amd.native.Engine.
 The packed / BN-folded device copy is a cache owned by the native handle and is
 rebuilt whenever a parameter or buffer changes (load_state_dict, .to(), in-place edit).
 
-Only the eval / label=None path exists natively (SURVEY.md 8b "mode semantics"):
-training-mode forward and the label branch raise -- there is no CPU or stock-torch
-fallback anywhere in this package.
+Backbone is eval-only (the reference never trains it, models/trainer.py:62-63); RecNet runs
+natively in eval() (label=None -> 2-tuple) and in train() mode (label given -> the 7-tuple,
+differentiable through the native backward).  There is no CPU or stock-torch fallback anywhere
+in this package.
 """
 import torch
 import torch.nn as nn
@@ -67,8 +68,36 @@ class _NativeModule(nn.Module):
     """Shared cache logic: one Engine per device, reloaded when any tensor changed."""
     _kind = None
 
+    def _tensors(self):
+        """The 402 / 121 parameter and buffer tensors, listed once.  Building a state_dict per forward cost 0.9 ms
+        (measured) -- more than a small-batch forward; reading 400 version counters costs 0.05 ms.  The list is dropped
+        whenever the module tree can have changed: _apply (.to(), .float(), ...), load_state_dict, attribute
+        assignment on this module; `invalidate_native_cache()` covers hand surgery on sub-modules."""
+        lst = self.__dict__.get('_native_tensors')
+        if lst is None:
+            lst = list(self.state_dict(keep_vars=True).values())
+            self.__dict__['_native_tensors'] = lst
+        return lst
+
+    def invalidate_native_cache(self):
+        self.__dict__.pop('_native_tensors', None)
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_native_cache()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate_native_cache()
+        return super().load_state_dict(*a, **k)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)):
+            self.invalidate_native_cache()
+        super().__setattr__(name, value)
+
     def _engine(self, device):
-        sig = (device.index, tuple((id(t), t._version) for t in self.state_dict(keep_vars=True).values()))
+        lst = self._tensors()
+        sig = (device.index, id(lst), tuple(t._version for t in lst))
         cache = self.__dict__.setdefault('_native_cache', {})
         ent = cache.get(device.index)
         if ent is None or ent[0] != sig:
@@ -96,7 +125,7 @@ class _NativeModule(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k == '_native_cache':
+            if k in ('_native_cache', '_native_tensors'):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         return new
@@ -272,6 +301,9 @@ class _RecNetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, slot, names, input, label, *params):
         ctx.eng, ctx.names = eng, names
+        # unused outputs (M_channel [n,512,512], pred_label [n,10575], ...) must reach backward as None, not as dense
+        # zero tensors the native backward would transpose and consume (> 270 MB of memset per iteration at n = 128)
+        ctx.set_materialize_grads(False)
         ctx.slot, ctx.ticket, ctx.live = slot
         ctx.shapes = [tuple(p.shape) for p in params]
         outs = eng.train_forward(input.detach(), label, groups=1, slot=ctx.slot)
@@ -284,7 +316,7 @@ class _RecNetTrainFn(torch.autograd.Function):
             raise RuntimeError('ffrnet_amd.RecNet: the activations of this forward were overwritten -- at most two '
                                'train-mode forwards may be outstanding before backward (models/trainer.py:144-145)')
         eng.train_zero_grad()
-        eng.train_backward([g if g is not None else None for g in gouts], slot=ctx.slot)
+        eng.train_backward(list(gouts), slot=ctx.slot)
         grads = []
         dev = eng.device
         for k, shp in zip(ctx.names, ctx.shapes):

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 KCLASS_NAMES = ['conv_igemm', 'stem', 'se', 'combine', 'head', 'selfsim', 'channel',
-                'space', 'layout', 'score', 'wino']
+                'space', 'layout', 'score', 'wino', 'wino_fused']
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -62,6 +62,8 @@ SYMBOLS = [
     ('ffr_lfw_fold_accuracy', C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     ('ffr_workspace_bytes', C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_reserve', C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    ('ffr_generation', C.c_ulonglong, [_P]),
+    ('ffr_probe_mfma_peak', C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     ('ffr_profile_enable', C.c_int, [_P, C.c_int]),
     ('ffr_profile_read', C.c_int, [_P, C.POINTER(KClassStat)]),
     ('ffr_op_conv', C.c_int, [_P, C.POINTER(ConvDesc), _P]),
@@ -290,6 +292,17 @@ class Engine(object):
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_reserve(self._h, n, h, w))
 
+    def generation(self):
+        """Changes whenever the handle released device memory a captured hipGraph may point into."""
+        return int(self.lib.ffr_generation(self._h))
+
+    def probe_mfma_peak(self, iters=20000):
+        """(TFLOP/s, shader clock in GHz) of a register-resident fp32-MFMA loop on this device."""
+        tf, ghz = C.c_double(0), C.c_double(0)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_probe_mfma_peak(self._h, iters, C.byref(tf), C.byref(ghz), self._stream()))
+        return tf.value, ghz.value
+
     def profile_enable(self, on=True):
         self._ck(self.lib.ffr_profile_enable(self._h, 1 if on else 0))
 
@@ -364,12 +377,28 @@ class Engine(object):
 
     # -- RecNet training step (include/ffrnet_train.h) --------------------------------------------
     N_CLASSES = 10575
+    validate_labels = True     # range check of class ids (the reference fails loudly in scatter_ / CrossEntropyLoss)
+
+    def _labels(self, label, n, device):
+        """int32 device copy of `label` after the checks the native kernels do not make: one id per image, every id in
+        [0, N_CLASSES).  A CPU tensor is checked before the copy (free); a device tensor costs one small sync, which
+        `validate_labels = False` removes."""
+        if not torch.is_tensor(label) or label.numel() != n:
+            raise RuntimeError('ffrnet_amd: expected %d class labels, got %s' %
+                               (n, list(label.shape) if torch.is_tensor(label) else type(label)))
+        if self.validate_labels and n:
+            lo, hi = int(label.min()), int(label.max())
+            if lo < 0 or hi >= self.N_CLASSES:
+                raise RuntimeError('ffrnet_amd: class label out of range [0, %d): min %d, max %d' % (self.N_CLASSES, lo, hi))
+        return label.reshape(-1).to(device, torch.int32).contiguous()
 
     def train_init(self, recnet_state_dict):
         """Device-resident training state (flat parameter / gradient / Adam buffers) from a RecNet state_dict."""
         arr, n, keep = self._descs(recnet_state_dict)
         self._ck(self.lib.ffr_train_init(self._h, arr, n))
         self._train_spec = {k: tuple(v.shape) for k, v in recnet_state_dict.items()}
+        # num_batches_tracked continues from the loaded values (the native counter counts updates since this call)
+        self._nbt0 = {k: int(v) for k, v in recnet_state_dict.items() if k.endswith('num_batches_tracked')}
 
     def train_info(self):
         p, g, n, nbt, step = _P(0), _P(0), C.c_size_t(0), C.c_longlong(0), C.c_int(0)
@@ -394,7 +423,7 @@ class Engine(object):
         sd = {}
         for k, shape in self._train_spec.items():
             if k.endswith('num_batches_tracked'):
-                sd[k] = torch.tensor(info['num_batches_tracked'], dtype=torch.long)
+                sd[k] = torch.tensor(info['num_batches_tracked'] + self._nbt0.get(k, 0), dtype=torch.long)
             elif k.endswith(('running_mean', 'running_var')):
                 sd[k] = self.train_get(k, 'running')
             else:
@@ -414,7 +443,7 @@ class Engine(object):
         n = featmap.size(0)
         if featmap.dim() != 4 or tuple(featmap.shape[1:]) != (512, 7, 7) or n % groups:
             raise RuntimeError('ffrnet_amd: RecNet input must be [G*N,512,7,7], got %s' % list(featmap.shape))
-        lab = label.to(featmap.device, torch.int32).contiguous()
+        lab = self._labels(label, n, featmap.device)
         dev = featmap.device
         shapes = dict(f_new=(n, 512), pred_loss=(n, self.N_CLASSES), pred_label=(n, self.N_CLASSES), M_space=(n, 49, 49),
                       M_channel=(n, 512, 512), feat_space=(n, 512, 7, 7), feat_channel=(n, 512, 7, 7))
@@ -470,7 +499,7 @@ class Engine(object):
         n = img_non.size(0)
         if tuple(img_non.shape[1:]) != (3, 112, 112) or img_ocl.shape != img_non.shape:
             raise RuntimeError('ffrnet_amd: training images must be [N,3,112,112] pairs')
-        lab = label.to(img_non.device, torch.int32).contiguous()
+        lab = self._labels(label, n, img_non.device)
         out = torch.empty(5, device=img_non.device, dtype=torch.float32)
         lw = (C.c_double * 4)(*[float(x) for x in loss_weight])
         with torch.cuda.device(self.device):
@@ -532,10 +561,17 @@ class GraphedEmbed(object):
     def __init__(self, engine, n):
         self.engine, self.n = engine, n
         dev = engine.device
-        engine.reserve(n)
         self.x = torch.zeros((n, 3, 112, 112), device=dev, dtype=torch.float32)
         self.f_new = torch.empty((n, 512), device=dev, dtype=torch.float32)
         self.f = torch.empty((n, 512), device=dev, dtype=torch.float32)
+        self.captures = 0
+        self._capture()
+
+    def _capture(self):
+        """The graph holds raw pointers into the handle's workspace and packed weights: it is only valid for the
+        allocation generation it was captured in (Engine.generation())."""
+        engine, dev = self.engine, self.engine.device
+        engine.reserve(self.n)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                      # warm-up outside the capture
@@ -544,11 +580,16 @@ class GraphedEmbed(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             engine.embed(self.x, out=(self.f_new, self.f))
+        self.generation = engine.generation()
+        self.captures += 1
 
     def __call__(self, x):
         _check_dev(x, 'x', (3, 112, 112))
         if x.size(0) != self.n:
             raise RuntimeError('GraphedEmbed was captured for batch %d, got %d' % (self.n, x.size(0)))
+        if self.engine.generation() != self.generation:
+            # a larger batch, a weight reload or ffr_train_init re-allocated what the graph points into
+            self._capture()
         self.x.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.f_new, self.f

@@ -130,8 +130,10 @@ enum {
     FFR_KC_SPACE = 7,
     FFR_KC_LAYOUT = 8,
     FFR_KC_SCORE = 9,
-    FFR_KC_WINO = 10,       /* Winograd F(4x4,3x3) input / output transforms */
-    FFR_KC_COUNT = 11
+    FFR_KC_WINO = 10,       /* Winograd F(4x4,3x3) input / output transforms (HBM-bound) */
+    FFR_KC_WINO_FUSED = 11, /* k_wino_fused: the 36 GEMMs + output transform of a Winograd conv (MFMA-bound; the
+                               dominant kernel of the forward) */
+    FFR_KC_COUNT = 12
 };
 typedef struct {
     int64_t launches;
@@ -142,6 +144,13 @@ typedef struct {
                                execute 36/144 of the direct MACs, plus tile padding)       */
 } ffr_kclass_stat;
 int ffr_profile_enable(ffr_handle* h, int on);
+/* Allocation generation: changes whenever device memory that a caller may have captured into a hipGraph (workspace
+ * arena, stream-K tickets, packed weights, training buffers) has been released and re-allocated.  A graph captured
+ * around ffr_embed must be re-captured when this value differs from the one read at capture time.               */
+unsigned long long ffr_generation(const ffr_handle* h);
+/* fp32-MFMA rate this device delivers on a register-resident v_mfma_f32_32x32x2_f32 loop (iters x 16 MFMAs per
+ * wave, 8 waves per CU) and the shader clock it holds meanwhile: the measured denominator of a roofline fraction. */
+int ffr_probe_mfma_peak(ffr_handle* h, int iters, double* tflops, double* clock_ghz, void* stream);
 int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out /* [FFR_KC_COUNT] */);
 
 /* ---- single operators (parity tests drive the kernels one at a time) -------------

@@ -14,6 +14,8 @@ from ffrnet_amd import synth
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch_losses as TL  # noqa: E402
 
 GRAD_TOL = 2e-4     # gradients: max-abs-err / max-abs-ref per tensor (fp32 re-association over <= 12544-row sums)
 
@@ -271,7 +273,7 @@ def test_native_trainer_step_matches_reference(specs, golden_dir):
     assert np.allclose(np.array([float(l) for l in items2]), g8['losses'], rtol=1e-4)
     # the same iteration with the loss items evaluated by torch ops instead of the native loss kernels
     tr3 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
-    items3 = tr3.step_torch_losses(non.cuda(), ocl.cuda(), label.cuda())
+    items3 = TL.step_torch_losses(tr3, non.cuda(), ocl.cuda(), label.cuda())
     assert np.allclose(np.array([float(l) for l in items3]), np.array([float(l) for l in items2]), rtol=1e-4)
     assert float(tr3.accuracy) == float(tr2.accuracy)
     for k in keys:
@@ -314,7 +316,6 @@ def test_recnet_shell_train_branch_two_iterations(specs):
     then a second iteration, which must see the moved parameters.  Held to the oracle's train_step."""
     import ffr_oracle as O
     import ffr_oracle_train as OT
-    from ffrnet_amd import train as T
     sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
     sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
     for k in sd_r:                      # smooth network (PReLU slope 1): no kink noise, tight tolerances
@@ -341,7 +342,7 @@ def test_recnet_shell_train_branch_two_iterations(specs):
         out_non = rec(fm_non.to(dev), label.to(dev))
         out_ocl = rec(fm_ocl.to(dev), label.to(dev))
         assert len(out_non) == 7 and out_non[1].shape == (4, 10575)
-        items = T.trainer_losses(out_non[0], out_ocl[0], out_non[1], out_ocl[1], out_non[5], out_ocl[5], out_non[6],
+        items = TL.trainer_losses(out_non[0], out_ocl[0], out_non[1], out_ocl[1], out_non[5], out_ocl[5], out_non[6],
                                  out_ocl[6], fm_non.to(dev), fe_non.to(dev), fe_ocl.to(dev), label.to(dev))
         assert np.allclose([float(l) for l in items], ref['losses'], rtol=2e-4), (it, [float(l) for l in items], ref['losses'])
         opt.zero_grad()

@@ -1,29 +1,52 @@
 #!/bin/bash
-# HBM traffic of k_igemm over a whole forward (separate --pmc passes, MI355X_MICROARCH.md: FETCH_SIZE
-# reads half of a wide coalesced stream on gfx950 -> doubled below; WRITE_SIZE exact). Run via gpurun.
+# HBM traffic and matrix-core counters of one forward at batch 256 (run via gpurun; copy the summary into profiles/).
+# Separate --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2); FETCH_SIZE reads half of a
+# wide coalesced stream on gfx950 -> doubled below, WRITE_SIZE is exact.  The program follows `--` directly.
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/pmc_bench
+OUT=$R/gpurun_out/pmc_bench
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_bench/$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>$R/gpurun_out/pmc_bench/$c.err
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+  d=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$d -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>$OUT/$d.err
 done
 python3 - <<PY
-import csv, glob, collections, json
-tot = collections.defaultdict(lambda: [0.0, 0])
-for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    for f in glob.glob('$R/gpurun_out/pmc_bench/%s/*/*counter_collection.csv' % c):
-        for r in csv.DictReader(open(f)):
-            k = 'igemm' if ('k_igemm' in r['Kernel_Name'] or 'k_gemm_stream' in r['Kernel_Name']) else r['Kernel_Name'].split('(')[0][-40:]
-            if r['Counter_Name'] == c:
-                tot[(k, c)][0] += float(r['Counter_Value']); tot[(k, c)][1] += 1
-out = {}
-for (k, c), (v, n) in sorted(tot.items()):
-    kb = v / n
-    out.setdefault(k, {})[c + '_KB_per_launch'] = kb
-    out[k]['launches'] = n
-ig = out.get('igemm', {})
-if ig:
-    ig['hbm_bytes_per_launch_corrected'] = (2 * ig.get('FETCH_SIZE_KB_per_launch', 0) + ig.get('WRITE_SIZE_KB_per_launch', 0)) * 1024
+import csv, glob, collections, json, hashlib
+R = '$R'
+sha = hashlib.sha256(open(R + '/ffr-net_amd/libffrnet_hip.so', 'rb').read()).hexdigest()
+STEPS = 3          # warmup 1 + steps 2 (the parity gate's batch-8 forward is excluded by its grid sizes below)
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob('$OUT/*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        if not k.startswith('ffr::'):
+            continue
+        tot[k][r['Counter_Name']] += float(r['Counter_Value'])
+        cnt[k][r['Counter_Name']] += 1
+out = {'so_sha256': sha, 'how': 'tools/pmc_bench.sh: rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 --warmup 1 '
+       '(3 forwards at batch 256 + one batch-8 parity forward); FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact',
+       'kernels': {}}
+gb = 0.0
+for k in sorted(tot):
+    e = {'launches': max(cnt[k].values())}
+    fk, wk = tot[k].get('FETCH_SIZE', 0.0), tot[k].get('WRITE_SIZE', 0.0)
+    e['hbm_bytes_total_corrected'] = (2 * fk + wk) * 1024
+    e['fetch_kb_per_launch'] = fk / max(1, cnt[k].get('FETCH_SIZE', 1))
+    e['write_kb_per_launch'] = wk / max(1, cnt[k].get('WRITE_SIZE', 1))
+    gb += e['hbm_bytes_total_corrected']
+    for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F32', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY',
+              'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE'):
+        if c in tot[k]:
+            e[c + '_per_launch'] = tot[k][c] / cnt[k][c]
+    out['kernels'][k] = e
+out['gb_per_step'] = round(gb / STEPS / 1e9, 2)
+d = out['kernels'].get('ffr::k_wino_fused')
+if d:
+    out['dominant'] = {'kernel': 'ffr::k_wino_fused', 'launches_per_step': d['launches'] // STEPS,
+                       'hbm_bytes_per_launch': int(d['hbm_bytes_total_corrected'] / d['launches'])}
+    if 'SQ_VALU_MFMA_BUSY_CYCLES_per_launch' in d and 'SQ_BUSY_CYCLES_per_launch' in d:
+        out['dominant']['mfma_busy_over_sq_busy'] = d['SQ_VALU_MFMA_BUSY_CYCLES_per_launch'] / d['SQ_BUSY_CYCLES_per_launch']
 print(json.dumps(out, indent=1))
-json.dump(out, open('$R/gpurun_out/pmc_bench/summary.json', 'w'), indent=1)
+json.dump(out, open('$OUT/summary.json', 'w'), indent=1)
 PY

@@ -4,7 +4,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import ffrnet_amd
-from ffrnet_amd import synth, train
+from ffrnet_amd import synth
+import torch_losses as train
 import test_gpu_train as T
 
 specs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g0_state_dict_keys.json')))
