@@ -631,7 +631,7 @@ int run_recnet(ffr_handle* h, const Work& w, int N, float* f_new, const RecDebug
         // ss_channel Gram + Conv4Channel (6 linears) + M_channel @ X, algorithmic (unfused) count
         const double fl = 2.0 * N * (512.0 * 512 * 49 + 512.0 * (561 * 32 + 5 * 32 * 512) + 512.0 * 512 * 49);
         Scope s(h, st, FFR_KC_CHANNEL, fl, 4.0 * N * (49 * 512 * 3));
-        HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st));
+        HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st, dbg ? dbg->ss_channel0 : nullptr, dbg ? dbg->M_channel0 : nullptr));
     }
     // Conv4Space (recnet.py:362-371)
     RC(conv_rec(h, w, h->sp[0], w.bufS, 576, nullptr, 0, w.s256a, 256, 0, 0, N, st));
@@ -1145,14 +1145,14 @@ int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, i
 }
 
 int ffr_recnet_debug(ffr_handle* h, const float* featmap_nchw, int N, float* ss_space, float* M_space, float* feat_space,
-                     float* feat_channel_raw, float* feat_channel, void* stream) {
+                     float* feat_channel_raw, float* feat_channel, float* ss_channel0, float* M_channel0, void* stream) {
     FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, true, N));
     if (!featmap_nchw) return fail(h, FFR_ERR_ARG, "featmap is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;
     RC(ensure_arena(h, N, 112, 112, &w));
     HIPCK(h, launch_nchw_to_nhwc(featmap_nchw, w.X, 512, N, 49, 512, st));
-    RecDebug d{ss_space, M_space, feat_space, feat_channel_raw, feat_channel};
+    RecDebug d{ss_space, M_space, feat_space, feat_channel_raw, feat_channel, ss_channel0, M_channel0};
     return run_recnet(h, w, N, nullptr, &d, st);
 }
 

@@ -202,7 +202,7 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w);
 struct U8In { const unsigned char* img; const unsigned char* flip; };
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
                 hipStream_t st, const U8In* u8 = nullptr, const float* x2 = nullptr, int n_split = 0);
-struct RecDebug { float *ss_space, *M_space, *feat_space, *feat_channel_raw, *feat_channel; };
+struct RecDebug { float *ss_space, *M_space, *feat_space, *feat_channel_raw, *feat_channel, *ss_channel0, *M_channel0; };
 int conv_rec(ffr_handle* h, const Work& w, const ConvW& L, const float* x, int in_pitch, const float* resid,
              int res_pitch, float* out, int out_pitch, int out_coff, int flags, int N, hipStream_t st);
 int run_recnet(ffr_handle* h, const Work& w, int N, float* f_new, const RecDebug* dbg, hipStream_t st);

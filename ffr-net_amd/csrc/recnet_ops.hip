@@ -91,7 +91,7 @@ hipError_t launch_selfsim_space(const float* X, float* bufS, int pitchS, float* 
 #define XT_LD 52
 __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict__ X, const ChannelPathWeights w,
                                                      const float* __restrict__ w1bT, float* __restrict__ bufF,
-                                                     int pitchF) {
+                                                     int pitchF, float* __restrict__ dbg_ss, float* __restrict__ dbg_M) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* XT = sm;                       // [512][52]  X transposed: channel-major
     float* inv = XT + 512 * XT_LD;        // [512] 1/max(|X_c|,eps)
@@ -116,6 +116,14 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
         inv[c1] = 1.0f / fmaxf(sqrtf(s1), 1e-12f);
     }
     __syncthreads();
+    if (dbg_ss && n == 0) {     // parity tests only: ss_channel of image 0 from the normalised vectors the path uses
+        for (int o = tid; o < 512 * 512; o += 256) {
+            const int c = o >> 9, cp = o & 511;
+            float s = 0.f;
+            for (int p = 0; p < 49; ++p) s += XT[c * XT_LD + p] * XT[cp * XT_LD + p];
+            dbg_ss[o] = s * inv[c] * inv[cp];
+        }
+    }
     // P2: G[p][j] = sum_c Xhat[p][c] * W1b[j][c]   (w1bT = [512][32])
     for (int o = tid; o < 49 * 32; o += 256) {
         const int p = o >> 5, j = o & 31;
@@ -224,6 +232,11 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
             for (int ks = 0; ks < 16; ++ks) z = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ks], HB[ct][ks], z, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 1.0f / (1.0f + __expf(-z[r]));
+            if (dbg_M && n == 0) {      // parity tests only: M_channel[c][c'] of image 0, straight from the accumulator tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dbg_M[(128 * wave + 32 * ct + mj) * 512 + cpt * 32 + (r & 3) + 8 * (r >> 2) + 4 * mh] = z[r];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 fc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[0][r], z[r], fc[ct][0], 0, 0, 0);
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
 
 // w.w1b is passed TRANSPOSED ([512][32]) by the engine
 hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF, int N,
-                               hipStream_t stream) {
+                               hipStream_t stream, float* dbg_ss, float* dbg_M) {
     static bool attr_done = false;
     const size_t lds = (size_t)(512 * XT_LD + 512 + 49 * 32) * 4;
     if (!attr_done) {
@@ -261,7 +274,7 @@ hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, floa
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_channel_path, dim3(N), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF);
+    hipLaunchKernelGGL(k_channel_path, dim3(N), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
     return hipGetLastError();
 }
 

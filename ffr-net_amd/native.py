@@ -69,7 +69,7 @@ SYMBOLS = [
     ('ffr_op_conv', C.c_int, [_P, C.POINTER(ConvDesc), _P]),
     ('ffr_op_conv3x3', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ('ffr_encoder_trunk_nhwc', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
-    ('ffr_recnet_debug', C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    ('ffr_recnet_debug', C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     # include/ffrnet_train.h
     ('ffr_op_convlayer_train', C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ('ffr_train_init', C.c_int, [_P, C.POINTER(TensorDesc), C.c_int]),
@@ -542,12 +542,13 @@ class Engine(object):
                  M_space=torch.empty((n, 49, 49), device=dev),
                  feat_space=torch.empty((n, 512, 7, 7), device=dev),
                  feat_channel_raw=torch.empty((n, 512, 7, 7), device=dev),
-                 feat_channel=torch.empty((n, 512, 7, 7), device=dev))
+                 feat_channel=torch.empty((n, 512, 7, 7), device=dev),
+                 ss_channel0=torch.empty((512, 512), device=dev), M_channel0=torch.empty((512, 512), device=dev))
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_recnet_debug(
                 self._h, _ptr(featmap), n, _ptr(o['ss_space']), _ptr(o['M_space']),
                 _ptr(o['feat_space']), _ptr(o['feat_channel_raw']), _ptr(o['feat_channel']),
-                self._stream()))
+                _ptr(o['ss_channel0']), _ptr(o['M_channel0']), self._stream()))
         return o
 
 

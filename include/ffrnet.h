@@ -190,12 +190,14 @@ int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x_nchw, int N, int H, int
                            int n_blocks, float* out_nhwc, void* stream);
 
 /* RecNet internals for image-level goldens: any pointer may be NULL.
- *   ss_space[N,49,49] M_space[N,49,49] M_channel is not materialised (fused);
+ *   ss_space[N,49,49] M_space[N,49,49]; ss_channel and M_channel are never stored by the fused channel path:
+ *   ss_channel0[512,512] / M_channel0[512,512] receive them for IMAGE 0 only (debug stores inside the kernel);
  *   feat_space[N,512,7,7] feat_channel_raw[N,512,7,7] (before ChannelFlipMerge)
  *   feat_channel[N,512,7,7] (after ChannelFlipMerge), all NCHW.                     */
 int ffr_recnet_debug(ffr_handle* h, const float* featmap_nchw, int N,
                      float* ss_space, float* M_space, float* feat_space,
-                     float* feat_channel_raw, float* feat_channel, void* stream);
+                     float* feat_channel_raw, float* feat_channel, float* ss_channel0, float* M_channel0,
+                     void* stream);
 
 #ifdef __cplusplus
 }

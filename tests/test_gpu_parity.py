@@ -20,7 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import ffr_oracle as O  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-3
+TOL = 1e-3          # the contract with the reference (BASELINE.json north_star)
+REG_TOL = 5e-5      # regression gate: the build measures 2-5e-6 end to end; a Winograd edge-tile or border-class-bias
+                    # slip that costs 1e-4 must fail here although it is inside the contract
 OP_TOL = 2e-5
 
 
@@ -168,12 +170,13 @@ def test_config1_embeddings_vs_golden(engine, golden_dir):
     f_new, feat_new = engine.recnet_forward(featmap)
     f_new2, f2 = engine.embed(x)
     torch.cuda.synchronize()
-    assert rel(f, torch.from_numpy(g['f'])) < TOL
-    assert rel(f_new, torch.from_numpy(g['f_new'])) < TOL
-    assert rel(featmap[0], torch.from_numpy(g['featmap0'])) < TOL
-    assert rel(feat_new[0], torch.from_numpy(g['feat_new0'])) < TOL
-    assert rel(f_new2, torch.from_numpy(g['f_new'])) < TOL
-    assert rel(f2, torch.from_numpy(g['f'])) < TOL
+    for tol in (TOL, REG_TOL):
+        assert rel(f, torch.from_numpy(g['f'])) < tol
+        assert rel(f_new, torch.from_numpy(g['f_new'])) < tol
+        assert rel(featmap[0], torch.from_numpy(g['featmap0'])) < tol
+        assert rel(feat_new[0], torch.from_numpy(g['feat_new0'])) < tol
+        assert rel(f_new2, torch.from_numpy(g['f_new'])) < tol
+        assert rel(f2, torch.from_numpy(g['f'])) < tol
     # per-row relative L2
     for a, b in ((f_new.cpu(), torch.from_numpy(g['f_new'])), (f.cpu(), torch.from_numpy(g['f']))):
         assert (((a - b).norm(dim=1) / b.norm(dim=1)).max().item()) < TOL
@@ -185,11 +188,15 @@ def test_recnet_internals_vs_golden(engine, golden_dir):
     fm = torch.from_numpy(g1['featmap0'])[None].cuda()
     d = engine.recnet_debug(fm)
     torch.cuda.synchronize()
-    assert rel(d['ss_space'][0], torch.from_numpy(g3['ss_space0'])) < TOL
-    assert rel(d['M_space'][0], torch.from_numpy(g3['M_space0'])) < TOL
-    assert rel(d['feat_space'][0], torch.from_numpy(g3['feat_space0'])) < TOL
-    assert rel(d['feat_channel_raw'][0], torch.from_numpy(g3['feat_channel_raw0'])) < TOL
-    assert rel(d['feat_channel'][0], torch.from_numpy(g3['feat_channel0'])) < TOL
+    for tol in (TOL, REG_TOL):
+        assert rel(d['ss_space'][0], torch.from_numpy(g3['ss_space0'])) < tol
+        assert rel(d['M_space'][0], torch.from_numpy(g3['M_space0'])) < tol
+        assert rel(d['feat_space'][0], torch.from_numpy(g3['feat_space0'])) < tol
+        assert rel(d['feat_channel_raw'][0], torch.from_numpy(g3['feat_channel_raw0'])) < tol
+        assert rel(d['feat_channel'][0], torch.from_numpy(g3['feat_channel0'])) < tol
+        # the two tensors the fused channel path never stores (models/recnet.py:402,406): debug stores for image 0
+        assert rel(d['ss_channel0'][::8, ::8], torch.from_numpy(g3['ss_channel0_s8'])) < tol
+        assert rel(d['M_channel0'][::8, ::8], torch.from_numpy(g3['M_channel0_s8'])) < tol
 
 
 def test_trunk_112x96(engine, golden_dir):
@@ -215,19 +222,72 @@ def test_ragged_batches_vs_oracle(engine, state_dicts, n):
     f_new, f = engine.embed(x.cuda())
     rf_new, rf = O.embed(sd_e, sd_r, x)
     assert rel(f_new, rf_new) < TOL and rel(f, rf) < TOL
+    assert rel(f_new, rf_new) < REG_TOL and rel(f, rf) < REG_TOL
 
 
-def test_batch_independence_full_size(engine):
-    """BASELINE batch 256: images are independent units, so image i of the batch must
-    equal image i embedded in a batch of 8 (size-independent property; the oracle is
-    too slow for 256 images in a unit test)."""
-    x = synth.synth_images(256, seed=124).cuda()
+def test_batch_independence_full_size(engine, state_dicts):
+    """BASELINE batch 256 -- the launch shapes the benchmark runs (k_wino_fused over 2..25 rounds of block tiles,
+    stream-K cut tiles of the stride-2 convolutions, the 3.7 GB transform workspace).  Images are independent units:
+    EVERY row of the batch must equal the same image embedded in a batch of 8, and a 32-row subset is held to the
+    oracle (which is too slow for all 256 in a unit test)."""
+    sd_e, sd_r = state_dicts
+    xc = synth.synth_images(256, seed=124)
+    x = xc.cuda()
     f_new, f = engine.embed(x)
-    idx = [0, 1, 100, 128, 200, 253, 254, 255]
-    g_new, g = engine.embed(x[idx].contiguous())
-    assert rel(f_new[idx], g_new) < 1e-5 and rel(f[idx], g) < 1e-5
+    f_new, f = f_new.clone(), f.clone()
+    for i in range(0, 256, 8):
+        g_new, g = engine.embed(x[i:i + 8].contiguous())
+        assert rel(f_new[i:i + 8], g_new) < 1e-5 and rel(f[i:i + 8], g) < 1e-5, i
+    idx = list(range(3, 256, 8))
+    rf_new, rf = O.embed(sd_e, sd_r, xc[idx])
+    assert rel(f_new[idx], rf_new) < REG_TOL and rel(f[idx], rf) < REG_TOL
     assert torch.isfinite(f_new).all() and torch.isfinite(f).all()
     assert ((f.norm(dim=1) - 1).abs() < 1e-4).all()
+    # a second run of the same batch is bitwise identical (no atomics, fixed reduction orders)
+    f_new2, f2 = engine.embed(x)
+    assert torch.equal(f_new2, f_new) and torch.equal(f2, f)
+
+
+def test_encoder_forward_and_trunk_112x96_full_size(engine, state_dicts):
+    """ffr_encoder_forward (NCHW featmap out, BASELINE configs[1]) and the 112x96 trunk at batch 256: every image
+    equals its batch-8 run; a subset is held to the oracle."""
+    sd_e, _ = state_dicts
+    for hw, want_f in (((112, 112), True), ((112, 96), False)):
+        xc = synth.synth_images(256, hw[0], hw[1], seed=126)
+        x = xc.cuda()
+        fm, f = engine.encoder_forward(x, want_f=want_f)
+        fm = fm.clone()
+        f = f.clone() if want_f else None
+        for i in range(0, 256, 8):
+            gm, g = engine.encoder_forward(x[i:i + 8].contiguous(), want_f=want_f)
+            assert rel(fm[i:i + 8], gm) < 1e-5, (hw, i)
+            if want_f:
+                assert rel(f[i:i + 8], g) < 1e-5, (hw, i)
+        idx = [0, 77, 128, 255]
+        rfm = O._bn(O.encoder_trunk(sd_e, xc[idx]), sd_e, 'bn')
+        assert rel(fm[idx], rfm) < REG_TOL, hw
+        assert torch.isfinite(fm).all()
+
+
+def test_se_module_isolated(engine, state_dicts):
+    """SEModule (pretrain/model_ir_se50.py:18-36) on its own: block 2's squeeze-excitation scale, recovered from
+    the trunk taps around it -- res * sigmoid(fc2(relu(fc1(avgpool(res))))) + shortcut -- against torch ops on the
+    device with the same weights.  Checks both squeeze sources (Winograd tile sums / separate pooling pass)."""
+    sd_e, _ = state_dicts
+    x = synth.synth_images(5, seed=91).cuda()
+    for blk in (1, 2, 9, 22):            # stride-1 units of stages 1, 1, 3, 4 (identity shortcut, SE from tile sums)
+        a = engine.encoder_trunk_nhwc(x, blk).permute(0, 3, 1, 2)            # block input, NCHW
+        b = engine.encoder_trunk_nhwc(x, blk + 1).permute(0, 3, 1, 2)        # block output
+        p = 'body.%d.res_layer.' % blk
+        w = {k[len(p):]: v.cuda() for k, v in sd_e.items() if k.startswith(p)}
+        r = F.batch_norm(a, w['0.running_mean'], w['0.running_var'], w['0.weight'], w['0.bias'], False, 0.0, 1e-5)
+        r = F.prelu(F.conv2d(r, w['1.weight'], None, 1, 1), w['2.weight'])
+        r = F.conv2d(r, w['3.weight'], None, 1, 1)
+        r = F.batch_norm(r, w['4.running_mean'], w['4.running_var'], w['4.weight'], w['4.bias'], False, 0.0, 1e-5)
+        s = torch.sigmoid(F.conv2d(F.relu(F.conv2d(r.mean((2, 3), keepdim=True), w['5.fc1.weight'])), w['5.fc2.weight']))
+        got_scale = ((b - a) / r).median(dim=3).values.median(dim=2).values      # (out - shortcut) / res per (n, c)
+        assert rel(got_scale, s[:, :, 0, 0]) < 1e-3, blk          # through a division: loose
+        assert rel(b, r * s + a) < REG_TOL, blk                   # the block as a whole: tight
 
 
 def test_module_shells_drop_in(state_dicts, golden_dir):

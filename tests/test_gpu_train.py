@@ -426,6 +426,32 @@ def test_training_full_size_properties(specs):
     assert 0.0 <= float(tr.accuracy) <= 1.0
 
 
+def test_train_forward_full_size_values(specs):
+    """BASELINE configs[4] per-GPU shape: 128 pairs = 256 images through the train-mode forward, VALUES checked.  The
+    oracle's restatement (torch ops) is evaluated on the device for this size -- an independent implementation (stock
+    torch / MIOpen kernels) of RecNet.forward(input, label), models/recnet.py:398-429, BatchNorm batch statistics per
+    group included -- on the very feature maps the native encoder produced."""
+    import ffr_oracle_train as OT
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    non, ocl, label = synth.synth_train_batch(128, seed=78)
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    eng.train_init(sd_r)
+    with torch.no_grad():
+        fm, _ = eng.encoder_forward(torch.cat((non, ocl)).cuda())
+    lab = label.cuda()
+    outs = eng.train_forward(fm, torch.cat((lab, lab)), groups=2)
+    sd_dev = {k: v.cuda() for k, v in sd_r.items()}
+    names = ('f_new', 'pred_loss', 'pred_label', 'M_space', 'M_channel', 'feat_space', 'feat_channel')
+    with torch.no_grad():
+        for g in range(2):
+            ref = OT.recnet_train_forward(sd_dev, fm[128 * g:128 * (g + 1)], lab.long(), None)
+            for name, got, want in zip(names, outs, ref):
+                got = got[128 * g:128 * (g + 1)]
+                assert rel(got.reshape(want.shape), want) < 2e-4, (g, name, rel(got.reshape(want.shape), want))
+
+
 @pytest.mark.parametrize('n', [1, 3])
 def test_train_forward_small_and_odd_batches(engine, specs, n):
     """Edge batches: one image per group (BatchNorm statistics over 49 positions only) and an odd count."""
