@@ -434,6 +434,30 @@ def test_hipgraph_replay_matches_eager(engine):
     assert torch.equal(h_new, e_new)
 
 
+def test_hipgraph_recaptured_when_the_handle_reallocates(state_dicts):
+    """A captured forward holds raw pointers into the workspace arena and the packed weights.  A larger batch regrows
+    the arena, a weight reload re-packs: the allocation generation changes and the graph is captured again instead of
+    replaying into freed memory (ffr_generation)."""
+    sd_e, sd_r = state_dicts
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    eng.load_recnet(sd_r)
+    x = synth.synth_images(2, seed=612).cuda()
+    want_new, want = (t.clone() for t in eng.embed(x))
+    g = ffrnet_amd.GraphedEmbed(eng, 2)
+    gen0 = eng.generation()
+    assert torch.equal(g(x)[0], want_new) and g.captures == 1
+    eng.embed(synth.synth_images(40, seed=613).cuda())           # arena regrowth
+    assert eng.generation() != gen0
+    a, b = g(x)
+    torch.cuda.synchronize()
+    assert g.captures == 2 and torch.equal(a, want_new) and torch.equal(b, want)
+    eng.load_recnet(sd_r)                                         # packed weights re-allocated
+    a, b = g(x)
+    torch.cuda.synchronize()
+    assert g.captures == 3 and torch.equal(a, want_new) and torch.equal(b, want)
+
+
 def test_bench_and_trainer_two_ranks_on_one_gpu():
     """The N > 1 code paths on hardware, with what a 1-GPU box allows: two ranks on cuda:0 over gloo (RCCL refuses two
     ranks on one device).  bench.py: all-gather of the embeddings, barrier, max-over-ranks timing, one JSON line from

@@ -426,6 +426,45 @@ def test_training_full_size_properties(specs):
     assert 0.0 <= float(tr.accuracy) <= 1.0
 
 
+def test_native_trainer_resume_is_exact(specs, tmp_path):
+    """Checkpoint / resume of the native trainer (models/trainer.py:201-224 layout): parameters, BatchNorm running
+    statistics, num_batches_tracked (continues from the checkpoint value), Adam moments and step count.  Two steps +
+    save + load into a fresh trainer + one step == three uninterrupted steps, bit for bit; labels are validated."""
+    from ffrnet_amd import checkpoint
+    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    non, ocl, label = (t.cuda() for t in synth.synth_train_batch(6, seed=88))
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
+    for _ in range(3):
+        tr.step(non, ocl, label)
+    want = tr.flat_params.clone()
+    want_sd = tr.state_dict()
+    tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
+    for _ in range(2):
+        tr.step(non, ocl, label)
+    path = str(tmp_path / '0000002.pth.gzip')
+    checkpoint.save_recnet_checkpoint(tr, path, extra_info={'epoch': 0, 'iter': 2})
+    ck = checkpoint.load(path)
+    nbt = [int(v) for k, v in ck['RecNet'].items() if k.endswith('num_batches_tracked')]
+    assert set(nbt) == {4} and ck['optimizer']['step'] == 2          # two BatchNorm batches (clean, occluded) per step
+    eng2 = ffrnet_amd.Engine(0)
+    eng2.load_encoder(sd_e)
+    tr2 = ffrnet_amd.NativeTrainer(eng2, ck['RecNet'], lr=1e-3)
+    tr2.load_optimizer_state_dict(ck['optimizer'])
+    tr2.step(non, ocl, label)
+    assert torch.equal(tr2.flat_params, want)
+    got_sd = tr2.state_dict()
+    for k in want_sd:
+        assert torch.equal(got_sd[k].cpu(), want_sd[k].cpu()), k
+    assert {int(v) for k, v in got_sd.items() if k.endswith('num_batches_tracked')} == {6}
+    with pytest.raises(RuntimeError):
+        tr2.step(non, ocl, label.clone().fill_(10575))               # class id out of range: loud, as the reference
+    with pytest.raises(RuntimeError):
+        tr2.step(non, ocl, label[:3])                                # one label per pair
+
+
 def test_train_forward_full_size_values(specs):
     """BASELINE configs[4] per-GPU shape: 128 pairs = 256 images through the train-mode forward, VALUES checked.  The
     oracle's restatement (torch ops) is evaluated on the device for this size -- an independent implementation (stock
