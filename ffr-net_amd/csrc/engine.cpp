@@ -297,14 +297,19 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         const long long T = (long long)c.N * th * tw;
         // GEMM + output transform in one kernel (wino_fused.hip): M never exists in memory
         static const bool fused_on = !(getenv("FFR_WINO_FUSED") && atoi(getenv("FFR_WINO_FUSED")) == 0);
-        if (fused_on && L.wuc && c.wino_stage == 0 && wino_chunked_floats(T, L.cin_pad) <= c.wino_cap && T < 0x7fffffffLL) {
+        // K <= 256: the fused kernel transforms its own input (V never exists in memory); larger K: separate transform
+        static const int phased_maxk = getenv("FFR_WF_PHASED_MAXK") ? atoi(getenv("FFR_WF_PHASED_MAXK")) : 256;
+        const double x_bytes = 4.0 * c.N * c.H * c.W * c.in_pitch;
+        const bool phased = L.cin_pad <= phased_maxk && x_bytes <= 1073741824.0;
+        if (fused_on && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
             if (c.took_wino) *c.took_wino = true;
-            {
+            if (!phased) {
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
                 HIPCK(h, launch_wino_in_chunked(c.x, c.winoV, c.N, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
             }
             WinoFusedArgs f{};
-            f.Vc = c.winoV; f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
+            f.Vc = phased ? nullptr : c.winoV; f.x = c.x; f.x_bytes = phased ? (unsigned)x_bytes : 0u; f.in_pitch = c.in_pitch; f.pad_mode = L.pad_mode;
+            f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
             f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
             f.cout_pad = L.cout_pad; f.cout_store = c.cout_store; f.out_pitch = c.out_pitch; f.out_coff = c.out_coff;

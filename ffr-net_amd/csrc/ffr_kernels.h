@@ -73,7 +73,10 @@ hipError_t launch_wino_out(const float* M, const float* bias, const float* slope
 hipError_t launch_wino_in_chunked(const float* x, float* Vc, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
                                   hipStream_t stream);
 struct WinoFusedArgs {
-    const float* Vc; const float* Uc;
+    const float* Vc; const float* Uc;       // Vc == null: the kernel transforms x itself (phased mode)
+    const float* x;                         // phased mode: input [N,H,W,in_pitch] ...
+    unsigned x_bytes;                       // ... and its size in bytes (<= 1 GiB; out-of-range reads return zeros)
+    int in_pitch, pad_mode;
     const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
     int N, H, W, nkc;                       // nkc = cin_pad / 8
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;

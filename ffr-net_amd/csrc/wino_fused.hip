@@ -30,9 +30,21 @@ namespace ffr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// v = B^T d for any vector width
+template <typename V>
+__device__ __forceinline__ void bt6t(const V d[6], V v[6]) {
+    v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    v[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+    v[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    v[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    v[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
 
 // v = B^T d (vector form, as in winograd.hip)
 __device__ __forceinline__ void bt6v(const f32x4 d[6], f32x4 v[6]) {
@@ -44,7 +56,6 @@ __device__ __forceinline__ void bt6v(const f32x4 d[6], f32x4 v[6]) {
     v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // y = A^T m on a channel pair (packed fp32)
 __device__ __forceinline__ void at6p(const f32x2 m[6], f32x2 y[4]) {
     const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
@@ -154,8 +165,15 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // ---- the fused GEMM + output transform ------------------------------------------------------------------------
 constexpr int WF_EPI_FLOATS = 36 * 32 * 32;  // the epilogue's E[xi][tile][32 channels] (147,456 B); the K loop uses no LDS
-constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 4) * 4;   // + bias table + tile table = 150,272 B
+constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias table + tile table = 150,784 B
 
+// PHASED = false: V comes pre-transformed from k_wino_in_c (global memory, fragment order).
+// PHASED = true : the block transforms its own input, 32 channels (4 K chunks) at a time, into LDS (147 KB, the
+//                 same bytes the epilogue uses later): V never exists in global memory.  The transform is NOT overlapped
+//                 with the MFMAs (one wave per SIMD, all registers taken) and costs ~13k cycles per block and 32 channels,
+//                 so it pays where the separate transform kernel costs more than that per block: K = 64, whose V
+//                 (0.46 .. 1.85 GB per layer) makes the round trip through HBM.
+template <bool PHASED>
 __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -182,28 +200,30 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     const int tid = threadIdx.x;
     const int n0 = nb * 64;
     float* const s_bias = smem + WF_EPI_FLOATS;                       // [9][64] border-class biases of this channel group
-    int* const s_tile = reinterpret_cast<int*>(s_bias + 9 * 64);     // [32][4]: origin pixel, valid rows | cols << 8, border rows, border cols
+    int* const s_tile = reinterpret_cast<int*>(s_bias + 9 * 64);     // [32][8]: origin pixel, valid rows | cols << 8, border rows, border cols, image base pixel, 4ty-1, 4tx-1
     for (int i = tid; i < (a.border_bias ? 9 : 1) * 64; i += 256) s_bias[i] = a.bias[(size_t)(i >> 6) * a.cout_pad + n0 + (i & 63)];
     if (tid < 32) {
         const long long t = (long long)mb * 32 + tid;
-        int pix0 = 0, vrc = 0, br = 0, bc = 0;
+        int pix0 = 0, vrc = 0, br = 0, bc = 0, ibase = 0, h0 = 0, w0 = 0;
         if (t < a.T) {
             const int tiles_img = a.th * a.tw;
             const int n = (int)(t / tiles_img);
             const int tr = (int)(t - (long long)n * tiles_img);
             const int ty = tr / a.tw, tx = tr - ty * a.tw;
             pix0 = (n * a.H + ty * 4) * a.W + tx * 4;
+            ibase = n * a.H * a.W; h0 = ty * 4 - 1; w0 = tx * 4 - 1;
             const int vr = a.H - ty * 4 < 4 ? a.H - ty * 4 : 4, vc = a.W - tx * 4 < 4 ? a.W - tx * 4 : 4;
             vrc = vr | (vc << 8);
             // row i of the tile is the map's top row iff ty == 0 && i == 0; its bottom row iff i == H-1-4ty
             br = (ty == 0 ? 1 : 0) | ((a.H - 1 - ty * 4) & 0xff) << 8;
             bc = (tx == 0 ? 1 : 0) | ((a.W - 1 - tx * 4) & 0xff) << 8;
         }
-        s_tile[tid * 4 + 0] = pix0; s_tile[tid * 4 + 1] = vrc; s_tile[tid * 4 + 2] = br; s_tile[tid * 4 + 3] = bc;
+        s_tile[tid * 8 + 0] = pix0; s_tile[tid * 8 + 1] = vrc; s_tile[tid * 8 + 2] = br; s_tile[tid * 8 + 3] = bc;
+        s_tile[tid * 8 + 4] = ibase; s_tile[tid * 8 + 5] = h0; s_tile[tid * 8 + 6] = w0;
     }
 
     // operand streams of this wave: one 16-byte fragment per lane, xi and K chunk (lane-linear in memory)
-    const float* vp = a.Vc + ((size_t)mb * nkc * 36 + 9 * wave) * 256 + lane * 4;
+    const float* vp = PHASED ? nullptr : a.Vc + ((size_t)mb * nkc * 36 + 9 * wave) * 256 + lane * 4;
     const float* up = a.Uc + ((size_t)nb * nkc * 36 + 9 * wave) * 512 + lane * 4;
     const int rowl = lane & 31;
 
@@ -221,13 +241,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
             for (int j = 0; j < 8; ++j) acc[j][nt][r] = 0.f;
         }
 
+#define FFR_PIN __builtin_amdgcn_sched_barrier(0)
+    if constexpr (!PHASED) {
     // fragment registers: slot j holds (V, U lo, U hi) of xi j for the K chunk that consumes it next
     f32x4 fv[9], fu[9][2];
     auto load = [&](int j, int part, const float* v, const float* u) {
         if (part == 0) fv[j] = *reinterpret_cast<const f32x4*>(v + j * 256);
         else fu[j][part - 1] = *reinterpret_cast<const f32x4*>(u + j * 512 + (part - 1) * 256);
     };
-#define FFR_PIN __builtin_amdgcn_sched_barrier(0)
     // ---- prologue: xi 0..7 of K chunk 0 in flight (xi 8 follows in step 0) ----
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -263,6 +284,124 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         up += 36 * 512;
     }
     chunk.template operator()<true>();
+    } else {
+    // ---- PHASED: per 32 input channels: input transform -> LDS, then 4 K chunks with the A fragments from LDS ----
+    // Transform role of a thread, twice per phase (tile halves sh = 0, 1): tile 16 sh + 4 wave + (lane >> 4), channel
+    // pair lane & 15 of the phase's 32 channels.  Sixteen lanes read the whole 128-byte line of a pixel (with 32-byte
+    // pieces per lane pair the texture path, not HBM, set the pace: 20k cycles per phase on 56x56 maps); two channels
+    // per thread keep the 36 patch values at 72 registers (four channels = 144 registers spilled the accumulators of
+    // xi 8 into the MFMA chunks: 7.9k instead of 5.1k cycles per K chunk).
+    const int tp = lane & 15;
+    f32x4 fu[9][2];
+    auto loadu = [&](int j, int part, const float* u) {
+        fu[j][part] = *reinterpret_cast<const f32x4*>(u + j * 512 + part * 256);
+    };
+    f32x4 af[2];
+    // LDS image of V: [K chunk c][xi][64 fragments][4]; the fragment of (half h, tile t) sits at position
+    // 32 h + (t & 24) + ((t + 2c + h) & 7): rotated inside groups of 8 so that the 16 lanes of one tile (8 x (c, h), two
+    // 8-byte halves each) write 16 different bank pairs; a wave's read of one (c, xi) is still one conflict-free KB
+    int aoff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aoff[c] = ((lane & 32) + (lane & 24) + ((lane + 2 * c + (lane >> 5)) & 7)) * 4;
+    auto reada = [&](int buf, int c, int j) {
+        af[buf] = *reinterpret_cast<const f32x4*>(smem + (c * 36 + 9 * wave + j) * 256 + aoff[c]);
+    };
+    __syncthreads();                                        // the tile table is visible
+    // The input is read through a buffer resource: a tap outside the map (zero padding) or a tile beyond T gets an
+    // offset past the end of the tensor, for which the hardware returns zeros -- no select, no branch.  (0x40000000 per
+    // invalid coordinate: the sums stay >= the tensor size, which the launcher limits to 1 GiB in this mode.)
+    constexpr unsigned OOB = 0x40000000u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const int nph = nkc >> 2;
+    if (a.trace) st1 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int ph = 0; ph < nph; ++ph) {
+        unsigned long long tp0 = 0;
+        if (a.trace) tp0 = __builtin_amdgcn_s_memtime();
+        const unsigned soff = (unsigned)(ph * 32) * 4u;                   // scalar: the phase's first channel
+#pragma unroll 1
+        for (int sh = 0; sh < 2; ++sh) {
+            // -- input transform of channels [32 ph + 2 tp, +2) of tile ttl: all 36 loads in flight, in place --
+            const int ttl = 16 * sh + 4 * wave + (lane >> 4);
+            const int tvrc = s_tile[ttl * 8 + 1];
+            const int tib = s_tile[ttl * 8 + 4], th0 = s_tile[ttl * 8 + 5], tw0 = s_tile[ttl * 8 + 6];
+            unsigned ro[6], co[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int hi = th0 + i, wi = tw0 + i;
+                bool rok, cok;
+                if (a.pad_mode == 1) {
+                    hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi); if (hi < 0) hi = 0;
+                    wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi); if (wi < 0) wi = 0;
+                    rok = tvrc != 0; cok = true;
+                } else {
+                    rok = tvrc != 0 && (unsigned)hi < (unsigned)a.H;
+                    cok = (unsigned)wi < (unsigned)a.W;
+                }
+                ro[i] = rok ? (unsigned)((tib + hi * a.W) * a.in_pitch + tp * 2) * 4u : OOB;
+                co[i] = cok ? (unsigned)(wi * a.in_pitch) * 4u : OOB;
+            }
+            f32x2 d[6][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)          // column by column: the first column pass starts under the other loads
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    d[i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, ro[i] + co[j], soff, 0));
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {          // columns: d[.][j] <- B^T d[.][j]
+                f32x2 col[6], v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+                bt6t(col, v);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d[i][j] = v[i];
+            }
+            // pair tp = (chunk c = tp >> 2, half h = (tp >> 1) & 1, 8-byte half of the fragment tp & 1)
+            const int tq = tp >> 1;
+            float* vout = smem + (((tq >> 1) * 36) * 64 + (tq & 1) * 32 + (ttl & 24) + ((ttl + tq) & 7)) * 4 + (tp & 1) * 2;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {          // rows: V[i][.] = d[i][.] B, straight into the fragment image
+                f32x2 v[6];
+                bt6t(d[i], v);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vout + (i * 6 + j) * 256) = v[j];
+                // the registers of the finished rows take this phase's first weight fragments
+                if (sh == 1 && i >= 2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { loadu((i - 2) * 2 + q, 0, up); loadu((i - 2) * 2 + q, 1, up); }
+                }
+            }
+        }
+        if (a.trace) se[0] += __builtin_amdgcn_s_memtime() - tp0;       // diagnostics: transform (before the barrier)
+        __syncthreads();
+        if (a.trace) se[1] += __builtin_amdgcn_s_memtime() - tp0;       // ... incl. the barrier
+        reada(0, 0, 0);
+        // -- 4 K chunks: 9 steps of 8 MFMAs; A fragment of the next step from LDS, weight fragments 8 steps ahead --
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int cur = (c * 9 + j) & 1;
+                const f32x4 av = af[cur], b0 = fu[j][0], b1 = fu[j][1];
+                const bool has_next = !(c == 3 && j == 8);
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int e = g >> 1, nt = g & 1;
+                    if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
+                    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
+                    if (g >= 1 && g < 3) {
+                        if (j == 0) loadu(8, g - 1, up);                                   // xi 8 of this chunk
+                        else if (c < 3) loadu(j - 1, g - 1, up + 36 * 512);                // xi j-1 of the next chunk
+                    }
+                    if (g == 4 && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
+                    FFR_PIN;
+                }
+            }
+            up += 36 * 512;
+        }
+        __syncthreads();                                    // everybody is done reading V before the next transform
+    }
+    }
 #undef FFR_PIN
     if (a.trace) st2 = __builtin_amdgcn_s_memtime();
 
@@ -284,12 +423,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
             for (int r = 0; r < 16; ++r)
                 smem[((9 * wave + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + rowl] = j < 8 ? acc[j][nt][r] : accv[nt][r];
         __syncthreads();
-        if (a.trace) se[2 * nt] = __builtin_amdgcn_s_memtime();
+        if (a.trace && !PHASED) se[2 * nt] = __builtin_amdgcn_s_memtime();
         // one (tile, 4 channels) per thread: a wave-instruction reads / stores 8 tiles x 128 bytes
         const int tl = (lane >> 3) + 8 * wave;
-        const int vrc = s_tile[tl * 4 + 1];
+        const int vrc = s_tile[tl * 8 + 1];
         if (vrc != 0) {                                                 // else: tile beyond T
-            const int pix0 = s_tile[tl * 4 + 0];
+            const int pix0 = s_tile[tl * 8 + 0];
             const int vr = vrc & 0xff, vc = vrc >> 8;
             const f32x4* e = reinterpret_cast<const f32x4*>(smem + tl * 32 + 4 * cq);
             f32x4 y[4][4];
@@ -320,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) bs[i][jj] = b0;
             } else {
-                const int br = s_tile[tl * 4 + 2], bc = s_tile[tl * 4 + 3];
+                const int br = s_tile[tl * 8 + 2], bc = s_tile[tl * 8 + 3];
                 int rc[4], cc[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -394,13 +533,16 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)t * a.cout_pad + cg) = psum;
             }
         }
-        if (a.trace) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
+        if (a.trace && !PHASED) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
     if (a.trace && lane == 0) {
         unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 10;
         tr[0] = st0; tr[1] = st1; tr[2] = st2; tr[3] = __builtin_amdgcn_s_memtime();
         tr[6] = se[0]; tr[7] = se[1]; tr[8] = se[2]; tr[9] = se[3];
+        if (PHASED) {       // per phase: transform, barrier wait (reported in the first two epilogue columns)
+            tr[6] = st2 + se[0] / (nkc >> 2); tr[7] = tr[6] + (se[1] - se[0]) / (nkc >> 2); tr[8] = tr[7]; tr[9] = tr[7];
+        }
         tr[4] = __builtin_amdgcn_s_memrealtime();
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -409,7 +551,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 }
 
 hipError_t wino_fused_init() {
-    return hipFuncSetAttribute((const void*)k_wino_fused, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)k_wino_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_wino_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
 }
 
 static int wf_grid(int mbn, int nbn) {      // inverse of the block decoding in k_wino_fused
@@ -429,7 +573,12 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
     a.T = (long long)a.N * a.th * a.tw;
     a.mbn = (int)((a.T + 31) / 32);
     a.nbn = a.cout_pad / 64;
-    hipLaunchKernelGGL(k_wino_fused, dim3(wf_grid(a.mbn, a.nbn)), dim3(256), WF_LDS_BYTES, stream, a);
+    if (a.Vc) {
+        hipLaunchKernelGGL(k_wino_fused<false>, dim3(wf_grid(a.mbn, a.nbn)), dim3(256), WF_LDS_BYTES, stream, a);
+    } else {
+        if (!a.x || a.nkc % 4 || a.x_bytes == 0 || a.x_bytes > 0x40000000u) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_wino_fused<true>, dim3(wf_grid(a.mbn, a.nbn)), dim3(256), WF_LDS_BYTES, stream, a);
+    }
     return hipGetLastError();
 }
 
