@@ -297,8 +297,9 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         const long long T = (long long)c.N * th * tw;
         // GEMM + output transform in one kernel (wino_fused.hip): M never exists in memory
         static const bool fused_on = !(getenv("FFR_WINO_FUSED") && atoi(getenv("FFR_WINO_FUSED")) == 0);
-        // K <= 256: the fused kernel transforms its own input (V never exists in memory); larger K: separate transform
-        static const int phased_maxk = getenv("FFR_WF_PHASED_MAXK") ? atoi(getenv("FFR_WF_PHASED_MAXK")) : 256;
+        // K <= 128: the fused kernel transforms its own input (V never exists in memory); larger K: separate transform
+        // kernel (measured at batch 256: 17.99 / 18.04 / 18.78 ms per forward for a limit of 64 / 128 / 256, 18.67 without)
+        static const int phased_maxk = getenv("FFR_WF_PHASED_MAXK") ? atoi(getenv("FFR_WF_PHASED_MAXK")) : 128;
         const double x_bytes = 4.0 * c.N * c.H * c.W * c.in_pitch;
         const bool phased = L.cin_pad <= phased_maxk && x_bytes <= 1073741824.0;
         if (fused_on && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {

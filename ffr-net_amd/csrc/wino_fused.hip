@@ -319,9 +319,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         unsigned long long tp0 = 0;
         if (a.trace) tp0 = __builtin_amdgcn_s_memtime();
         const unsigned soff = (unsigned)(ph * 32) * 4u;                   // scalar: the phase's first channel
-#pragma unroll 1
+        // -- input transform of channels [32 ph + 2 tp, +2) of this thread's two tiles: all 72 loads in flight first --
+        f32x2 d[2][6][6];
+#pragma unroll
         for (int sh = 0; sh < 2; ++sh) {
-            // -- input transform of channels [32 ph + 2 tp, +2) of tile ttl: all 36 loads in flight, in place --
             const int ttl = 16 * sh + 4 * wave + (lane >> 4);
             const int tvrc = s_tile[ttl * 8 + 1];
             const int tib = s_tile[ttl * 8 + 4], th0 = s_tile[ttl * 8 + 5], tw0 = s_tile[ttl * 8 + 6];
@@ -341,20 +342,23 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 ro[i] = rok ? (unsigned)((tib + hi * a.W) * a.in_pitch + tp * 2) * 4u : OOB;
                 co[i] = cok ? (unsigned)(wi * a.in_pitch) * 4u : OOB;
             }
-            f32x2 d[6][6];
 #pragma unroll
             for (int j = 0; j < 6; ++j)          // column by column: the first column pass starts under the other loads
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
-                    d[i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, ro[i] + co[j], soff, 0));
+                    d[sh][i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, ro[i] + co[j], soff, 0));
+        }
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            const int ttl = 16 * sh + 4 * wave + (lane >> 4);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {          // columns: d[.][j] <- B^T d[.][j]
                 f32x2 col[6], v[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+                for (int i = 0; i < 6; ++i) col[i] = d[sh][i][j];
                 bt6t(col, v);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) d[i][j] = v[i];
+                for (int i = 0; i < 6; ++i) d[sh][i][j] = v[i];
             }
             // pair tp = (chunk c = tp >> 2, half h = (tp >> 1) & 1, 8-byte half of the fragment tp & 1)
             const int tq = tp >> 1;
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {          // rows: V[i][.] = d[i][.] B, straight into the fragment image
                 f32x2 v[6];
-                bt6t(d[i], v);
+                bt6t(d[sh][i], v);
 #pragma unroll
                 for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vout + (i * 6 + j) * 256) = v[j];
                 // the registers of the finished rows take this phase's first weight fragments
