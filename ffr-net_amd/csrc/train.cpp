@@ -289,6 +289,11 @@ struct TrainState {
     double *p_sss, *p_ssc, *p_vec, *p_ce;
     int* hit;
     bool loss_grads_ready = false;
+    // gradient buckets of the data-parallel exchange: contiguous ranges of the flat buffer in the order the backward
+    // finishes them (classifier, Conv4Merge, ChannelFlipMerge, Conv4Channel, Conv4Space); one event per bucket
+    static const int NBUCKET = 5;
+    size_t bucket_off[NBUCKET + 1] = {0, 0, 0, 0, 0, 0};     // ascending offsets: sp | fm | mg | channel | classifier | end
+    hipEvent_t bucket_ev[NBUCKET] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -523,6 +528,7 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
         HIPCK(h, launch_normalize_bwd(t->dfn, 512, c.fn, c.fnorm, df_in, t->df, 512, 0, imgs, st));
         df = t->df;
     }
+    HIPCK(h, hipEventRecord(t->bucket_ev[4], st));          // classifier.weight gradient is final
     if (df) HIPCK(h, launch_avgpool_bwd(df, nullptr, t->dFeatNew, imgs, 512, st));
     else HIPCK(h, hipMemsetAsync(t->dFeatNew, 0, (size_t)rows * 512 * 4, st));
     // external gradients wrt feat_space / feat_channel (NCHW) -> extM [rows][1024]
@@ -539,10 +545,12 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     RC(LB(t->mg[2], c.mg[2], t->dFeatNew, 512, 0, t->d512a, 512, 512, nullptr, 0, 0));
     RC(LB(t->mg[1], c.mg[1], t->d512a, 512, 0, t->d512b, 512, 512, t->dFeatNew, 512, 0));
     RC(LB(t->mg[0], c.mg[0], t->d512b, 512, 0, t->dBufM, 1024, 1024, t->extM, 1024, 0));
+    HIPCK(h, hipEventRecord(t->bucket_ev[2], st));          // Conv4Merge gradients are final
     // ---- ChannelFlipMerge ------------------------------------------------------------------------
     RC(LB(t->fm[2], c.fm[2], t->dBufM, 1024, 512, t->d512a, 512, 512, nullptr, 0, 0));
     RC(LB(t->fm[1], c.fm[1], t->d512a, 512, 0, t->d512b, 512, 512, t->dBufM, 1024, 512));
     RC(LB(t->fm[0], c.fm[0], t->d512b, 512, 0, t->dF, 1024, 1024, nullptr, 0, 0));
+    HIPCK(h, hipEventRecord(t->bucket_ev[1], st));          // ChannelFlipMerge
     // ---- M_channel: feat_channel_raw = M_channel @ X -------------------------------------------
     HIPCK(h, launch_cat_to_draw(t->dF, t->dRawt, imgs, st));
     RC(gemm_batched(h, w, t->dRawt, 512 * 64, 64, c.Xt, 512 * 64, 512, t->dMc, 512, (long long)512 * 512, 512, imgs, st));
@@ -574,6 +582,7 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     }
     HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h1pre, 64, 64, t->a[0], crow, t->rowdot, t->ga[0], 1, st));
     RC(lin_backward(h, t, w, ln[0], t->d32a, 64, c.cat, 576, crow, nullptr, 0, st));
+    HIPCK(h, hipEventRecord(t->bucket_ev[3], st));          // Conv4Channel (linears, biases, PReLU slopes)
     // ---- M_space: feat_space = X_flat @ M_space ------------------------------------------------
     HIPCK(h, launch_space_apply_bwd(t->dBufM, 1024, 0, c.X, t->dms, imgs, st));
     if (og.M_space) HIPCK(h, launch_mspace_grad_in(og.M_space, t->dms, imgs, st));
@@ -588,6 +597,7 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     RC(LB(t->sp[2], c.sp[2], t->d256c, 256, 0, t->d256a, 256, 256, nullptr, 0, 0));
     RC(LB(t->sp[1], c.sp[1], t->d256a, 256, 0, t->d256b, 256, 256, t->d256c, 256, 0));
     RC(LB(t->sp[0], c.sp[0], t->d256b, 256, 0, nullptr, 0, 0, nullptr, 0, 0));
+    HIPCK(h, hipEventRecord(t->bucket_ev[0], st));          // Conv4Space: the whole flat gradient buffer is final
     return FFR_OK;
 }
 
@@ -628,6 +638,7 @@ void train_free(ffr_handle* h) {
     hipDeviceSynchronize();
     for (auto& c : h->train->ctx) free_ctx(c);
     if (h->train->scratch_mem) hipFree(h->train->scratch_mem);
+    for (auto& e : h->train->bucket_ev) if (e) hipEventDestroy(e);
     free_list(h->train->allocs);
     delete h->train;
     h->train = nullptr;
@@ -717,9 +728,13 @@ int ffr_train_init(ffr_handle* h, const ffr_tensor_desc* td, int n) {
             running_floats += (size_t)2 * L.cout_pad;
         }
     };
+    t->bucket_off[0] = t->n_flat;
     def_layers(SP_DEF, 9, t->sp);
+    t->bucket_off[1] = t->n_flat;
     def_layers(FM_DEF, 3, t->fm);
+    t->bucket_off[2] = t->n_flat;
     def_layers(MG_DEF, 3, t->mg);
+    t->bucket_off[3] = t->n_flat;
     for (int i = 0; i < 6; ++i) {
         Lin& l = t->lin[i];
         l.in = LIN_IN[i]; l.out = LIN_OUT[i]; l.in_pad = round_up(l.in, 32); l.out_pad = round_up(l.out, 64);
@@ -728,7 +743,11 @@ int ffr_train_init(ffr_handle* h, const ffr_tensor_desc* td, int n) {
         add_seg(t, p + ".bias", SEG_VEC, l.out, 1, l.out_pad, 1);
     }
     for (int i = 0; i < 3; ++i) add_seg(t, "Conv4Channel." + std::to_string(ACT_IDX[i]) + ".func.weight", SEG_VEC, 512, 1, 512, 1);
+    t->bucket_off[4] = t->n_flat;
     add_seg(t, "classifier.weight", SEG_LIN, N_CLASSES, 512, CLS_PAD, 512);
+    t->bucket_off[5] = t->n_flat;
+    for (auto& e : t->bucket_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipEventCreate failed");
     // ---- device buffers ---------------------------------------------------------------------------
     RC(dev_alloc_t(h, t->allocs, t->n_flat, &t->P));
     RC(dev_alloc_t(h, t->allocs, t->n_flat, &t->Gr));
@@ -930,6 +949,27 @@ int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_
     return FFR_OK;
 }
 
+
+// Gradient buckets for overlapping the data-parallel exchange with the backward: bucket i is the range
+// [offsets[i], offsets[i+1]) of the flat gradient buffer; order[k] is the k-th bucket the backward completes.
+int ffr_train_buckets(ffr_handle* h, int* n, size_t* offsets, int* order) {
+    TrainState* t;
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
+    if (n) *n = TrainState::NBUCKET;
+    if (offsets) for (int i = 0; i <= TrainState::NBUCKET; ++i) offsets[i] = t->bucket_off[i];
+    static const int ORDER[TrainState::NBUCKET] = {4, 2, 1, 3, 0};
+    if (order) for (int i = 0; i < TrainState::NBUCKET; ++i) order[i] = ORDER[i];
+    return FFR_OK;
+}
+
+// Makes `stream` wait until the last recorded backward has finished bucket i (hipStreamWaitEvent; no host sync).
+int ffr_train_bucket_wait(ffr_handle* h, int i, void* stream) {
+    TrainState* t;
+    FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
+    if (i < 0 || i >= TrainState::NBUCKET) return fail(h, FFR_ERR_ARG, "ffr_train_bucket_wait: bad bucket");
+    HIPCK(h, hipStreamWaitEvent((hipStream_t)stream, t->bucket_ev[i], 0));
+    return FFR_OK;
+}
 
 int ffr_train_option(ffr_handle* h, const char* name, int value) {
     TrainState* t;

@@ -83,6 +83,8 @@ SYMBOLS = [
     ('ffr_train_adam_step', C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     ('ffr_train_debug_copy', C.c_int, [_P, C.c_int, C.c_char_p, _P, C.c_size_t]),
     ('ffr_train_option', C.c_int, [_P, C.c_char_p, C.c_int]),
+    ('ffr_train_buckets', C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    ('ffr_train_bucket_wait', C.c_int, [_P, C.c_int, _P]),
     ('ffr_train_export', C.c_int, [_P, C.c_int, C.c_char_p, _P, _P]),
     ('ffr_train_import', C.c_int, [_P, C.c_int, C.c_char_p, _P, _P]),
     ('ffr_train_losses', C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_double), _P, _P]),
@@ -506,6 +508,18 @@ class Engine(object):
             self._ck(self.lib.ffr_train_iteration(self._h, _ptr(img_non.contiguous()), _ptr(img_ocl.contiguous()), _ptr(lab), n,
                                                   lw, _ptr(out), self._stream()))
         return out
+
+    def train_buckets(self):
+        """[(offset, count)] of the gradient buckets in the order the backward finishes them, with their ids."""
+        n = C.c_int(0)
+        off = (C.c_size_t * 6)()
+        order = (C.c_int * 5)()
+        self._ck(self.lib.ffr_train_buckets(self._h, C.byref(n), off, order))
+        return [(int(order[k]), int(off[order[k]]), int(off[order[k] + 1] - off[order[k]])) for k in range(n.value)]
+
+    def train_bucket_wait(self, i, stream):
+        """`stream` (torch.cuda.Stream) waits on the device until the enqueued backward has finished bucket i."""
+        self._ck(self.lib.ffr_train_bucket_wait(self._h, int(i), C.c_void_p(stream.cuda_stream)))
 
     def train_option(self, name, value):
         self._ck(self.lib.ffr_train_option(self._h, name.encode(), int(value)))

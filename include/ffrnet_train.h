@@ -103,7 +103,16 @@ int ffr_train_iteration(ffr_handle* h, const float* img_non, const float* img_oc
 int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, double eps, double weight_decay,
                         double clip_value, void* stream);
 
-/* Options of the training state. "winograd" (default 1): the 3x3 convolutions of the forward and of the data
+/* Gradient buckets for overlapping the data-parallel exchange with the backward (replaces what
+ * nn.parallel.data_parallel's gather + backward does implicitly, models/trainer.py:70-72).  The flat gradient buffer
+ * is cut into *n contiguous ranges [offsets[i], offsets[i+1]) (floats); order[k] is the k-th range the backward
+ * finishes (classifier first, Conv4Space last).  After ffr_train_iteration / ffr_train_backward has been ENQUEUED,
+ * ffr_train_bucket_wait(h, i, comm_stream) makes comm_stream wait (hipStreamWaitEvent, no host sync) for range i to be
+ * final, so an all-reduce of that range enqueued on comm_stream runs under the rest of the backward.  n = 5.   */
+int ffr_train_buckets(ffr_handle* h, int* n, size_t* offsets /* [n + 1] */, int* order /* [n] */);
+int ffr_train_bucket_wait(ffr_handle* h, int i, void* stream);
+
+/* Options of the training state. "adam_step": sets Adam's step count (resume).  "winograd" (default 1): the 3x3 convolutions of the forward and of the data
  * gradient with >= 128 input channels run as Winograd F(4x4,3x3) (weights transformed on the device from the
  * live master weights at every use); 0 = direct implicit GEMM everywhere.  "fold_channel" (default 1): the
  * Linear(32,512) -> Linear(512,32) pairs of Conv4Channel (models/recnet.py:376-380) run as their 32x32 product

@@ -19,11 +19,21 @@ def worker(rank, world, port, q):
     specs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g0_state_dict_keys.json')))
     eng = ffrnet_amd.Engine(0)
     eng.load_encoder(synth.synth_state_dict(specs['encoder']))
-    tr = ffrnet_amd.NativeTrainer(eng, synth.synth_state_dict(specs['recnet']), lr=1e-3)
-    tr.broadcast_params(0)
     non, ocl, label = (t.cuda() for t in synth.synth_train_batch(4, seed=700 + rank))
+    # one blocking all-reduce of the whole flat buffer after the backward ...
+    tr = ffrnet_amd.NativeTrainer(eng, synth.synth_state_dict(specs['recnet']), lr=1e-3, overlap=False)
+    tr.broadcast_params(0)
+    tr.step(non, ocl, label)
+    torch.cuda.synchronize()
+    p_blocking = tr.flat_params.clone()
+    # ... and the bucketed exchange on a second stream under the backward must give the same parameters
+    tr = ffrnet_amd.NativeTrainer(eng, synth.synth_state_dict(specs['recnet']), lr=1e-3, overlap=True)
+    tr.broadcast_params(0)
     items = tr.step(non, ocl, label)
     torch.cuda.synchronize()
+    assert torch.equal(tr.flat_params, p_blocking), 'overlapped exchange differs from the blocking one'
+    buckets = eng.train_buckets()
+    assert sum(c for _, _, c in buckets) == tr.flat_grads.numel() and [b for b, _, _ in buckets] == [4, 2, 1, 3, 0]
     p = tr.flat_params.cpu()
     q.put((rank, [float(x) for x in items], float(p.double().sum()), float(p.double().abs().sum()), p[::100003].tolist()))
     dist.destroy_process_group()
