@@ -291,7 +291,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
     const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
     static const bool wino_on = !(getenv("FFR_WINO") && atoi(getenv("FFR_WINO")) == 0);
-    if (L.wu && c.winoV && c.tile == 0 && (c.wino_mode == 1 || (c.wino_mode < 0 && wino_on))) {
+    if (L.wu && c.winoV && c.tile == 0 && (c.wino_mode >= 1 || (c.wino_mode < 0 && wino_on))) {
         // Winograd F(4x4,3x3): input transform -> 36 batched GEMMs [T x cin] * [cin x cout] -> output transform
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
         const long long T = (long long)c.N * th * tw;
@@ -302,7 +302,13 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         static const int phased_maxk = getenv("FFR_WF_PHASED_MAXK") ? atoi(getenv("FFR_WF_PHASED_MAXK")) : 128;
         const double x_bytes = 4.0 * c.N * c.H * c.W * c.in_pitch;
         const bool phased = L.cin_pad <= phased_maxk && x_bytes <= 1073741824.0;
-        if (fused_on && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
+        // One block tile (32 tiles x 64 channels, all 36 xi) occupies a whole CU and cannot be cut: a launch with fewer
+        // block tiles than CUs leaves matrix cores idle, where the batched-GEMM path balances K-tiles over every CU
+        // (Conv4Space at batch 256: 32..128 block tiles, 1.07 ms fused vs 0.55 ms unfused).  wino_mode 1 forces fused.
+        static const long long min_blocks = getenv("FFR_WF_MINBLOCKS") ? atoll(getenv("FFR_WF_MINBLOCKS")) : 200;
+        const long long block_tiles = ((T + 31) / 32) * (L.cout_pad / 64);
+        const bool want_fused = c.wino_mode == 1 || (c.wino_mode < 0 && block_tiles >= min_blocks);
+        if (fused_on && want_fused && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
             if (c.took_wino) *c.took_wino = true;
             if (!phased) {
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
@@ -1127,7 +1133,7 @@ int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, 
         c.out = out; c.out_pitch = cout; c.out_coff = 0; c.cout_store = cout;
         c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
         c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
-        c.wino_mode = use_wino ? 1 : 0;
+        c.wino_mode = use_wino;        // 0 direct, 1 Winograd fused (k_wino_fused), 2 Winograd as batched GEMM + transform kernels
         rc = run_conv(h, L, c, st);
         if (rc == FFR_OK && use_wino && (size_t)36 * N * ((H + 3) / 4) * ((W + 3) / 4) * (L.cin_pad > L.cout_pad ? L.cin_pad : L.cout_pad) > w.wino_cap)
             rc = fail(h, FFR_ERR_NOMEM, "Winograd scratch too small for this test shape");

@@ -164,7 +164,7 @@ struct ConvCall {
     float* partial; size_t partial_cap;   // floats
     int* tickets; size_t tickets_cap;
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
-    int wino_mode = -1;                            // -1 auto (env FFR_WINO), 0 never, 1 whenever packed
+    int wino_mode = -1;                            // -1 auto (env FFR_WINO; fused kernel when the launch fills the chip), 0 never, 1 Winograd, fused kernel when packed for it, 2 Winograd, transform kernels + batched GEMM
     int wino_stage = 0;                            // 0 whole conv; 1 stop after the GEMM (M stays in winoM); 2 V is ready in winoV
     bool* took_wino = nullptr;                     // set to true when the Winograd path ran
     float* tile_sums = nullptr;                    // Winograd path only: per-tile sums of the stored outputs [T][cout_pad]

@@ -340,7 +340,7 @@ class Engine(object):
             self._ck(self.lib.ffr_op_conv3x3(self._h, _ptr(x_nhwc), n, hh, ww, cin, C.c_void_p(wh.data_ptr()),
                                              C.c_void_p(bh.data_ptr()),
                                              C.c_void_p(sh.data_ptr()) if sh is not None else C.c_void_p(0),
-                                             wh.size(0), pad_mode, 1 if use_wino else 0,
+                                             wh.size(0), pad_mode, int(use_wino),
                                              _ptr(resid.contiguous()) if resid is not None else C.c_void_p(0),
                                              _ptr(out), self._stream()))
         return out

@@ -177,7 +177,8 @@ int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution from RAW weights (host, [cout][cin][3][3] as torch stores them,
  * bias[cout], optional PReLU slope[cout]) on x[N,H,W,cin] NHWC (device, cin % 32 == 0), packed on
- * the fly.  use_wino: 1 = Winograd F(4x4,3x3) + batched GEMM, 0 = direct implicit GEMM.  Test hook
+ * the fly.  use_wino: 0 = direct implicit GEMM, 1 = Winograd F(4x4,3x3) with GEMM and output transform in one kernel
+ * (k_wino_fused; input transform inside it for cin <= 128), 2 = Winograd as transform kernels around a batched GEMM.  Test hook
  * that holds both paths to torch's conv2d.  out[N,H,W,cout] NHWC device, cout % 4 == 0.         */
 int ffr_op_conv3x3(ffr_handle* h, const float* x_nhwc, int N, int H, int W, int cin,
                    const float* w_host, const float* bias_host, const float* slope_host, int cout,

@@ -111,6 +111,9 @@ def test_conv_operator(engine, case):
 WINO_CASES = [
     # N, H, W, cin, cout, pad_mode, prelu, resid
     (3, 14, 14, 256, 256, 0, True, False),
+    (5, 56, 56, 64, 64, 0, True, False),      # cin <= 128: the fused kernel transforms its own input (zero padding)
+    (9, 7, 7, 128, 192, 1, True, True),       # ... with reflect padding, 3 channel groups, tiles beyond the last image
+    (2, 30, 22, 96, 64, 0, False, True),      # ... ragged map, cin not a multiple of 64
     (2, 28, 28, 128, 128, 0, False, False),
     (5, 7, 7, 512, 512, 1, True, True),       # 7x7: tiles hang over the edge, reflect padding
     (2, 13, 10, 128, 64, 0, True, True),      # ragged H, W
@@ -136,11 +139,12 @@ def test_winograd_conv_matches_direct_and_torch(engine, case):
     if resid:
         ref = ref + r.permute(0, 3, 1, 2)
     rd = r.cuda() if resid else None
-    got_w = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, True, rd).permute(0, 3, 1, 2).cpu()
-    got_d = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, False, rd).permute(0, 3, 1, 2).cpu()
+    got_d = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, 0, rd).permute(0, 3, 1, 2).cpu()
     assert rel(got_d, ref) < OP_TOL
-    assert rel(got_w, ref) < 1e-4          # Winograd F(4,3) in fp32: measured ~2e-6
-    assert rel(got_w, got_d) < 1e-4
+    for use_wino in (1, 2):                # fused kernel (the network's path for full launches) / transform kernels + batched GEMM
+        got_w = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, use_wino, rd).permute(0, 3, 1, 2).cpu()
+        assert rel(got_w, ref) < 1e-4, use_wino          # Winograd F(4,3) in fp32: measured ~2e-6
+        assert rel(got_w, got_d) < 1e-4, use_wino
 
 
 def test_trunk_stage_taps(engine, state_dicts, golden_dir):

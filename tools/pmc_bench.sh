@@ -41,12 +41,18 @@ for k in sorted(tot):
             e[c + '_per_launch'] = tot[k][c] / cnt[k][c]
     out['kernels'][k] = e
 out['gb_per_step'] = round(gb / STEPS / 1e9, 2)
-d = out['kernels'].get('ffr::k_wino_fused')
-if d:
-    out['dominant'] = {'kernel': 'ffr::k_wino_fused', 'launches_per_step': d['launches'] // STEPS,
-                       'hbm_bytes_per_launch': int(d['hbm_bytes_total_corrected'] / d['launches'])}
-    if 'SQ_VALU_MFMA_BUSY_CYCLES_per_launch' in d and 'SQ_BUSY_CYCLES_per_launch' in d:
-        out['dominant']['mfma_busy_over_sq_busy'] = d['SQ_VALU_MFMA_BUSY_CYCLES_per_launch'] / d['SQ_BUSY_CYCLES_per_launch']
+fused = [k for k in out['kernels'] if 'k_wino_fused' in k]
+if fused:
+    tot_b = sum(out['kernels'][k]['hbm_bytes_total_corrected'] for k in fused)
+    tot_l = sum(out['kernels'][k]['launches'] for k in fused)
+    # 3 forwards at batch 256 + the batch-8 parity forward: 4 forwards' worth of launches, ~3.03 forwards' worth of bytes
+    out['dominant'] = {'kernel': 'ffr::k_wino_fused<false|true>', 'launches_per_step': tot_l // 4,
+                       'hbm_bytes_per_launch': int(tot_b / (3 * (tot_l // 4)))}
+    mb = sum(out['kernels'][k].get('SQ_VALU_MFMA_BUSY_CYCLES_per_launch', 0) * out['kernels'][k]['launches'] for k in fused)
+    ga = sum(out['kernels'][k].get('GRBM_GUI_ACTIVE_per_launch', 0) * out['kernels'][k]['launches'] for k in fused)
+    if mb and ga:
+        # SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs of the chip, GRBM_GUI_ACTIVE the 8 XCDs
+        out['dominant']['mfma_busy_frac_of_kernel_time'] = round((mb / 1024.0) / (ga / 8.0), 4)
 print(json.dumps(out, indent=1))
 json.dump(out, open('$OUT/summary.json', 'w'), indent=1)
 PY
