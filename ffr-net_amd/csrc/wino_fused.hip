@@ -270,10 +270,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 const int e = g >> 1, nt = g & 1;
                 if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
                 else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
-                // fillers, one per MFMA gap
-                if (g >= 1 && g < 4) {
-                    if (j == 0) load(8, g - 1, vp, up);                                        // xi 8 of this chunk
-                    else if (!LAST) load(j - 1, g - 1, vp + 36 * 256, up + 36 * 512);          // xi j-1 of the next chunk
+                // the step's three loads go out back to back in ONE MFMA gap: an MFMA whose gap carries vector-memory
+                // instructions issues ~8 cycles late plus ~14 per load (measured: 5.30k cycles per K chunk with one load in
+                // each of three gaps, 5.15k with three loads in one gap, 4.70k without loads)
+                if (g == 1) {
+#pragma unroll
+                    for (int part = 0; part < 3; ++part) {
+                        if (j == 0) load(8, part, vp, up);                                     // xi 8 of this chunk
+                        else if (!LAST) load(j - 1, part, vp + 36 * 256, up + 36 * 512);       // xi j-1 of the next chunk
+                    }
                 }
                 FFR_PIN;
             }
@@ -399,9 +404,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                     const int e = g >> 1, nt = g & 1;
                     if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
                     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
-                    if (g >= 1 && g < 3) {
-                        if (j == 0) loadu(8, g - 1, up);                                   // xi 8 of this chunk
-                        else if (c < 3) loadu(j - 1, g - 1, up + 36 * 512);                // xi j-1 of the next chunk
+                    if (g == 1) {              // both weight loads of the step in one MFMA gap (see the unphased loop)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {
+                            if (j == 0) loadu(8, part, up);                                // xi 8 of this chunk
+                            else if (c < 3) loadu(j - 1, part, up + 36 * 512);             // xi j-1 of the next chunk
+                        }
                     }
                     if (g == 4 && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
                     FFR_PIN;
