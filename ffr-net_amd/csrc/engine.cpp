@@ -345,9 +345,17 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     if (q[4] > r1) r1 = q[4];
                     if (q[4] < r0) r0 = q[4];
                 }
-                fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
-                                "epilogue %.0f cyc (to LDS %.0f, transform+store %.0f, barrier+to LDS %.0f, transform+store %.0f, end %.0f) | block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt,
-                        loop / cnt, loop / cnt / f.nkc, epi / cnt, ep[0] / cnt, ep[1] / cnt, ep[2] / cnt, ep[3] / cnt, ep[4] / cnt, (double)(r1 - r0) / 100.0);
+                if (phased)      // the kernel reports per phase: input transform, wait at the barrier behind it
+                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel): %d live blocks of %d | per block (wave 0): "
+                                    "prologue %.0f loop %.0f = %d phases x (transform %.0f + barrier %.0f + 4 K chunks of %.0f) epilogue %.0f cyc | "
+                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt, loop / cnt, f.nkc / 4,
+                            ep[0] / cnt, ep[1] / cnt, (loop / cnt / (f.nkc / 4) - ep[0] / cnt - ep[1] / cnt) / 4.0, epi / cnt,
+                            (double)(r1 - r0) / 100.0);
+                else
+                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
+                                    "epilogue %.0f cyc (to LDS %.0f, transform+store %.0f, barrier+to LDS %.0f, transform+store %.0f, end %.0f) | block ends spread over %.1f us\n",
+                            c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt, loop / cnt, loop / cnt / f.nkc, epi / cnt, ep[0] / cnt, ep[1] / cnt,
+                            ep[2] / cnt, ep[3] / cnt, ep[4] / cnt, (double)(r1 - r0) / 100.0);
                 if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
                 return FFR_OK;
             }

@@ -14,42 +14,47 @@ python3 - <<PY
 import csv, glob, collections, json, hashlib
 R = '$R'
 sha = hashlib.sha256(open(R + '/ffr-net_amd/libffrnet_hip.so', 'rb').read()).hexdigest()
-STEPS = 3          # warmup 1 + steps 2 (the parity gate's batch-8 forward is excluded by its grid sizes below)
+STEPS = 3          # warmup 1 + steps 2 forwards at batch 256; the batch-8 parity forward in front of them is cut off
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob('$OUT/*/*/*counter_collection.csv'):
-    for r in csv.DictReader(open(f)):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
+    stems = sorted({int(r['Dispatch_Id']) for r in rows if 'k_stem' in r['Kernel_Name']})
+    first = stems[1] if len(stems) > STEPS else stems[0]          # dispatch id of the first batch-256 forward
+    for r in rows:
+        if int(r['Dispatch_Id']) < first:
+            continue
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')
         if not k.startswith('ffr::'):
             continue
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[k][r['Counter_Name']] += 1
-out = {'so_sha256': sha, 'how': 'tools/pmc_bench.sh: rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 --warmup 1 '
-       '(3 forwards at batch 256 + one batch-8 parity forward); FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact',
-       'kernels': {}}
+out = {'so_sha256': sha, 'how': 'tools/pmc_bench.sh: rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 --warmup 1: the 3 '
+       'forwards at batch 256 (the batch-8 parity forward is excluded); FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact. '
+       'FETCH_SIZE counts L2 misses, Infinity-Cache hits included (MI355X_MICROARCH.md): re-reads of a 151 MB V by the other XCDs '
+       'appear here although they need not reach HBM.', 'kernels': {}}
 gb = 0.0
 for k in sorted(tot):
-    e = {'launches': max(cnt[k].values())}
+    e = {'launches_per_step': max(cnt[k].values()) / STEPS}
     fk, wk = tot[k].get('FETCH_SIZE', 0.0), tot[k].get('WRITE_SIZE', 0.0)
-    e['hbm_bytes_total_corrected'] = (2 * fk + wk) * 1024
+    e['hbm_gb_per_step_corrected'] = round((2 * fk + wk) * 1024 / STEPS / 1e9, 3)
     e['fetch_kb_per_launch'] = fk / max(1, cnt[k].get('FETCH_SIZE', 1))
     e['write_kb_per_launch'] = wk / max(1, cnt[k].get('WRITE_SIZE', 1))
-    gb += e['hbm_bytes_total_corrected']
+    gb += (2 * fk + wk) * 1024 / STEPS
     for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_F32', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_INST_ANY',
               'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE'):
         if c in tot[k]:
             e[c + '_per_launch'] = tot[k][c] / cnt[k][c]
     out['kernels'][k] = e
-out['gb_per_step'] = round(gb / STEPS / 1e9, 2)
+out['gb_per_step'] = round(gb / 1e9, 2)
 fused = [k for k in out['kernels'] if 'k_wino_fused' in k]
 if fused:
-    tot_b = sum(out['kernels'][k]['hbm_bytes_total_corrected'] for k in fused)
-    tot_l = sum(out['kernels'][k]['launches'] for k in fused)
-    # 3 forwards at batch 256 + the batch-8 parity forward: 4 forwards' worth of launches, ~3.03 forwards' worth of bytes
-    out['dominant'] = {'kernel': 'ffr::k_wino_fused<false|true>', 'launches_per_step': tot_l // 4,
-                       'hbm_bytes_per_launch': int(tot_b / (3 * (tot_l // 4)))}
-    mb = sum(out['kernels'][k].get('SQ_VALU_MFMA_BUSY_CYCLES_per_launch', 0) * out['kernels'][k]['launches'] for k in fused)
-    ga = sum(out['kernels'][k].get('GRBM_GUI_ACTIVE_per_launch', 0) * out['kernels'][k]['launches'] for k in fused)
+    lps = sum(out['kernels'][k]['launches_per_step'] for k in fused)
+    gbs = sum(out['kernels'][k]['hbm_gb_per_step_corrected'] for k in fused)
+    out['dominant'] = {'kernel': 'ffr::k_wino_fused<false|true>', 'launches_per_step': lps, 'hbm_gb_per_step': round(gbs, 3),
+                       'hbm_bytes_per_launch': int(gbs * 1e9 / lps)}
+    mb = sum(out['kernels'][k].get('SQ_VALU_MFMA_BUSY_CYCLES_per_launch', 0) * out['kernels'][k]['launches_per_step'] for k in fused)
+    ga = sum(out['kernels'][k].get('GRBM_GUI_ACTIVE_per_launch', 0) * out['kernels'][k]['launches_per_step'] for k in fused)
     if mb and ga:
         # SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs of the chip, GRBM_GUI_ACTIVE the 8 XCDs
         out['dominant']['mfma_busy_frac_of_kernel_time'] = round((mb / 1024.0) / (ga / 8.0), 4)
