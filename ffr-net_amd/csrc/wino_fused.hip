@@ -1,7 +1,7 @@
-// Winograd F(4x4,3x3) convolution with the 36 batched GEMMs AND the output transform in ONE kernel
-// (reference convolutions: pretrain/model_ir_se50.py:67,69 and models/recnet.py:65,82).
+// Winograd F(4x4,3x3) convolution with the 36 batched GEMMs AND the output transform (and, for cin <= 128, the input
+// transform) in ONE kernel (reference convolutions: pretrain/model_ir_se50.py:67,69 and models/recnet.py:65,82).
 //
-//   k_wino_in_c  :  X[N,H,W,pitch] --B^T d B--> Vc, stored in the chunk order the GEMM streams
+//   k_wino_in_c  :  X[N,H,W,pitch] --B^T d B--> Vc, stored in the MFMA-fragment order the GEMM streams (cin >= 256)
 //   k_wino_fused :  for a group of 32 tiles x 64 output channels, ALL 36 xi:
 //                       M[xi] = V[xi] U[xi]^T on the fp32 matrix cores, accumulators stay in registers,
 //                       then A^T M A + bias(border class) + PReLU + residual (+ sigmoid, SE tile sums) -> out
@@ -10,20 +10,17 @@
 // k_wino_out read it back (26 GB per forward at batch 256) -- and two of the three launches per convolution go.
 //
 // Work split of a block (256 threads, one wave per SIMD): wave w owns xi in [9w, 9w+9) for all 32 tiles x 64
-// channels: 18 accumulator tiles of 32x32 = 288 VGPRs.  Nothing is shared between the waves during the K loop:
-// wave w streams only V[xi] and U[xi] of its own xi, so the K loop has NO workgroup barrier; each wave runs a
-// private LDS ring of 9 slots (one per xi: 1 KB of V + 2 KB of U per 8-channel K chunk) filled by LDS-DMA
-// (global_load_lds_dwordx4) one whole K chunk ahead and retired with counted s_waitcnt vmcnt.
+// channels: 18 accumulator tiles of 32x32 = 288 registers.  Nothing is shared between the waves during the K loop:
+// wave w needs only V[xi] and U[xi] of its own xi, and the MFMA operand of a lane is 16 contiguous bytes (4 k-values of
+// one row), so V and U are stored in exactly that order -- [group][8-channel K chunk][xi][64 lanes][4 floats] -- and a
+// fragment is ONE coalesced global_load_dwordx4 per lane straight into the register the MFMA reads: no LDS, no
+// barrier, no LDS-DMA in the K loop.  Lane l carries row l & 31 and k = 4 (l >> 5) + e for the e-th of the four
+// v_mfma_f32_32x32x2_f32 a load feeds (A and B use the same order).  Nine fragment slots per wave are reloaded one step
+// after their use, 8 steps ahead of the next.
 //
-// Operand images: one 8-channel chunk of 32 rows is 1 KB = 64 pieces of 16 B, piece(row, h) = 2 row + (h ^ ((row>>3)&1)),
-// h = which half of the 8 channels.  Lane l of a wave reads piece(l & 31, l >> 5) with ds_read_b128: conflict free,
-// and the four floats feed four v_mfma_f32_32x32x2_f32 (lanes 0-31 carry k = e, lanes 32-63 k = 4 + e; A and B use the
-// same order).  The images are produced in this order in global memory (k_wino_in_c, host packer), so the DMA is a
-// straight lane-linear copy.
-//
-// Epilogue: the 36 x 32 x 64 products of the block go through LDS in four passes of 8 tiles (73.7 KB each, the ring
-// is dead by then); a thread then owns (tile, channel) pairs, applies A^T m A and the convolution epilogue and stores
-// 64 consecutive channels per wave-instruction.
+// Epilogue: the 36 x 32 x 64 products of the block go through LDS in two passes of 32 channels (147 KB, which the K
+// loop does not use); a thread then owns (tile, 4 channels), applies A^T m A and the convolution epilogue and stores 16
+// bytes per pixel; a wave-store covers 8 tiles x 128 bytes.  DESIGN.md 3.2 has the measurements behind each choice.
 #include "ffr_kernels.h"
 
 namespace ffr {
@@ -424,9 +421,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     if (a.trace) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue ----------------------------------------------------------------------------------------
-    // One wave per SIMD: this phase is bound by instruction issue (~4.5 cycles each), so it is written for few
-    // instructions: two passes (one per 32-channel half), whole accumulator tiles per pass, 8-byte LDS reads, packed
-    // fp32 math on channel pairs, per-tile geometry from a small LDS table, one 8-byte store per pixel and lane.
+    // One wave per SIMD: this phase is bound by instruction issue (~4.5 cycles each, packed fp32 twice that), so it is
+    // written for few instructions: two passes (one per 32-channel half), whole accumulator tiles per pass, 16-byte LDS
+    // reads, packed fp32 math on four channels, per-tile geometry from a small LDS table, one 16-byte store per pixel
+    // and lane, no branches.
     // the inline-asm MFMAs are invisible to hipcc's hazard recognizer: their results must not be read for 18 cycles
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     const int hsel = lane >> 5;
