@@ -360,9 +360,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 return FFR_OK;
             }
             Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec);
-            static const bool dual_on = !(getenv("FFR_WF_DUAL") && atoi(getenv("FFR_WF_DUAL")) == 0);
-            if (phased && dual_on) HIPCK(h, launch_wino_dual(f, st));      // cin <= 128: two 32x32 workgroups per CU
-            else HIPCK(h, launch_wino_fused(f, st));
+            HIPCK(h, launch_wino_fused(f, st));
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
             return FFR_OK;
         }
@@ -739,7 +737,6 @@ int ffr_create(ffr_handle** out, int device) {
     hipError_t e = igemm_init();
     if (e == hipSuccess) e = gemm_stream_init();
     if (e == hipSuccess) e = wino_fused_init();
-    if (e == hipSuccess) e = wino_dual_init();
     if (e != hipSuccess) {
         hipFree(z); delete h;
         return fail(nullptr, FFR_ERR_HIP, "igemm_init: %s", hipGetErrorString(e));

@@ -86,9 +86,6 @@ struct WinoFusedArgs {
 };
 int wino_fused_blocks(const WinoFusedArgs& a);
 hipError_t wino_fused_init();
-// the same convolution for cin <= 128 with 32 tiles x 32 channels per workgroup, two workgroups per CU (wino_dual.hip)
-hipError_t wino_dual_init();
-hipError_t launch_wino_dual(WinoFusedArgs a, hipStream_t stream);
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream);
 inline size_t wino_chunked_floats(long long T, int cin_pad) { return (size_t)((T + 31) / 32) * 32 * 36 * cin_pad; }
 
