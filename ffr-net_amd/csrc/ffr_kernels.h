@@ -80,6 +80,7 @@ struct WinoFusedArgs {
     const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
     int N, H, W, nkc;                       // nkc = cin_pad / 8
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
+    int map_v;                              // block -> tile mapping: 1 = the channel groups of a tile group share an XCD (V from its L2)
     int th, tw, mbn, nbn;                   // filled by the launcher
     long long T;
     unsigned long long* trace;              // diagnostics (FFR_WF_TRACE): 10 words per wave, or null

@@ -178,11 +178,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // block -> (tile group mb, channel group nb).  Blocks b and b + 8 share an XCD (round-robin dispatch) and with it
-    // a 4 MB L2: each XCD works on as few channel groups as possible, so that its slice of U (36 x cin x 64 floats, read
-    // by every block of the XCD once per tile group) stays in that L2 and only V streams through it (speed only)
+    // a 4 MB L2.  map_v (default): the channel groups of one tile group are neighbours on ONE XCD and run at the same
+    // time, so V is fetched into that L2 once; the blocks of an XCD walk through K in step, so the chunk of U they all
+    // need (73.7 KB per channel group) is in the L2 as well.  Otherwise: as few channel groups per XCD as possible (its
+    // slice of U stays in the L2, V is re-read by the XCD of every channel group).  Speed only.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     int nb, mb;
-    if (a.nbn % 8 == 0) {
+    if (a.map_v) {          // all channel groups of a tile group on one XCD, next to each other in dispatch order
+        nb = idx % a.nbn; mb = (idx / a.nbn) * 8 + xcd;
+    } else if (a.nbn % 8 == 0) {
         const int r = a.nbn >> 3;
         nb = xcd * r + idx % r; mb = idx / r;
     } else if (8 % a.nbn == 0) {
@@ -572,7 +576,8 @@ hipError_t wino_fused_init() {
     return hipFuncSetAttribute((const void*)k_wino_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
 }
 
-static int wf_grid(int mbn, int nbn) {      // inverse of the block decoding in k_wino_fused
+static int wf_grid(int mbn, int nbn, int map_v) {      // inverse of the block decoding in k_wino_fused
+    if (map_v) return (mbn + 7) / 8 * 8 * nbn;
     if (nbn % 8 == 0) return mbn * nbn;
     if (8 % nbn == 0) { const int per = 8 / nbn; return 8 * ((mbn + per - 1) / per); }
     return (mbn + 7) / 8 * 8 * nbn;
@@ -580,7 +585,7 @@ static int wf_grid(int mbn, int nbn) {      // inverse of the block decoding in 
 
 int wino_fused_blocks(const WinoFusedArgs& a) {
     const long long T = (long long)a.N * ((a.H + 3) / 4) * ((a.W + 3) / 4);
-    return wf_grid((int)((T + 31) / 32), a.cout_pad / 64);
+    return wf_grid((int)((T + 31) / 32), a.cout_pad / 64, a.map_v);
 }
 
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
@@ -590,10 +595,10 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
     a.mbn = (int)((a.T + 31) / 32);
     a.nbn = a.cout_pad / 64;
     if (a.Vc) {
-        hipLaunchKernelGGL(k_wino_fused<false>, dim3(wf_grid(a.mbn, a.nbn)), dim3(256), WF_LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(k_wino_fused<false>, dim3(wf_grid(a.mbn, a.nbn, a.map_v)), dim3(256), WF_LDS_BYTES, stream, a);
     } else {
         if (!a.x || a.nkc % 4 || a.x_bytes == 0 || a.x_bytes > 0x40000000u) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_wino_fused<true>, dim3(wf_grid(a.mbn, a.nbn)), dim3(256), WF_LDS_BYTES, stream, a);
+        hipLaunchKernelGGL(k_wino_fused<true>, dim3(wf_grid(a.mbn, a.nbn, a.map_v)), dim3(256), WF_LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }
