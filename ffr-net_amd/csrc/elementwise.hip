@@ -157,34 +157,86 @@ __global__ __launch_bounds__(256) void k_se_pool(const float* __restrict__ res, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ part, int S, int HW, int C,
+// All weights a thread needs (its rows of fc1, its rows of fc2) are requested BEFORE the partial sums are read: the three
+// dependent phases then wait for ONE memory latency instead of one per phase and fc1 row (14 -> 5 us per launch, 24 launches
+// per forward).  Summation orders are those of the plain loops: bitwise identical results.
+template <int C>
+__global__ __launch_bounds__(256) void k_se_fc(const float* __restrict__ part, int S, int HW,
                                               const float* __restrict__ fc1, const float* __restrict__ fc2,
                                               float* __restrict__ scale) {
-    __shared__ float s_mean[512];
-    __shared__ float s_hid[32];
+    constexpr int HID = C / 16;                         // 4..32
+    constexpr int RW = HID / 4;                         // fc1 rows per wave: 1..8
+    constexpr int CL = C / 64;                          // fc1 values per lane and row: 1..8
+    constexpr int CT = (C + 255) / 256;                 // channels per thread: 1..2
+    __shared__ float s_mean[C];
+    __shared__ float s_hid[HID];
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
-    const float inv = 1.0f / (float)HW;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int g = 0; g < S; ++g) s += part[((size_t)n * S + g) * C + c];
-        s_mean[c] = s * inv;
-    }
-    __syncthreads();
-    const int hid = C >> 4;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < hid; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += fc1[j * C + c] * s_mean[c];
-        s = wave_sum(s);
-        if (lane == 0) s_hid[j] = s > 0.f ? s : 0.f;
+    float w1[RW][CL], w2[CT][HID];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int k = 0; k < CL; ++k) w1[r][k] = fc1[(wave + 4 * r) * C + lane + 64 * k];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int j = 0; j < HID; j += 4) {             // a thread's fc2 row is contiguous: 16-byte loads
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (tid + 256 * t < C) v = *reinterpret_cast<const f32x4*>(fc2 + (size_t)(tid + 256 * t) * HID + j);
+            w2[t][j] = v[0]; w2[t][j + 1] = v[1]; w2[t][j + 2] = v[2]; w2[t][j + 3] = v[3];
+        }
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int c = tid + 256 * t;
+        if (c < C) {
+            float s = 0.f;
+            const float* pp = part + (size_t)n * S * C + c;
+            int g = 0;
+            for (; g + 8 <= S; g += 8) {            // eight loads in flight, added in order
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = pp[(size_t)(g + k) * C];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
+            for (; g < S; ++g) s += pp[(size_t)g * C];
+            s_mean[c] = s * inv;
+        }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
         float s = 0.f;
-        for (int j = 0; j < hid; ++j) s += fc2[c * hid + j] * s_hid[j];
-        scale[(size_t)n * C + c] = 1.0f / (1.0f + __expf(-s));
+#pragma unroll
+        for (int k = 0; k < CL; ++k) s += w1[r][k] * s_mean[lane + 64 * k];
+        s = wave_sum(s);
+        if (lane == 0) s_hid[wave + 4 * r] = s > 0.f ? s : 0.f;
     }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int c = tid + 256 * t;
+        if (c < C) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < HID; ++j) s += w2[t][j] * s_hid[j];
+            scale[(size_t)n * C + c] = 1.0f / (1.0f + __expf(-s));
+        }
+    }
+}
+
+static hipError_t launch_se_fc_any(const float* part, int N, int S, int HW, int C, const float* fc1, const float* fc2,
+                                   float* scale, hipStream_t stream) {
+    switch (C) {
+        case 64: hipLaunchKernelGGL(k_se_fc<64>, dim3(N), dim3(256), 0, stream, part, S, HW, fc1, fc2, scale); break;
+        case 128: hipLaunchKernelGGL(k_se_fc<128>, dim3(N), dim3(256), 0, stream, part, S, HW, fc1, fc2, scale); break;
+        case 256: hipLaunchKernelGGL(k_se_fc<256>, dim3(N), dim3(256), 0, stream, part, S, HW, fc1, fc2, scale); break;
+        case 512: hipLaunchKernelGGL(k_se_fc<512>, dim3(N), dim3(256), 0, stream, part, S, HW, fc1, fc2, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 int se_slices(int N, int HW) {
@@ -200,17 +252,14 @@ hipError_t launch_se(const float* res, int N, int HW, int C, const float* fc1, c
     if (C > 512 || (C & 63)) return hipErrorInvalidValue;
     const int S = se_slices(N, HW);
     hipLaunchKernelGGL(k_se_pool, dim3(N, S), dim3(256), 0, stream, res, HW, C, S, part);
-    hipLaunchKernelGGL(k_se_fc, dim3(N), dim3(256), 0, stream, part, S, HW, C, fc1, fc2, scale);
-    return hipGetLastError();
+    return launch_se_fc_any(part, N, S, HW, C, fc1, fc2, scale, stream);
 }
 
 // the second half alone: `part` [N][S][C] was already written by the producer of `res` (k_wino_out, one partial
 // sum per 4x4 output tile)
 hipError_t launch_se_fc(const float* part, int N, int S, int HW, int C, const float* fc1, const float* fc2, float* scale,
                         hipStream_t stream) {
-    if (C > 512 || (C & 63)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_se_fc, dim3(N), dim3(256), 0, stream, part, S, HW, C, fc1, fc2, scale);
-    return hipGetLastError();
+    return launch_se_fc_any(part, N, S, HW, C, fc1, fc2, scale, stream);
 }
 
 // ---------------------------------------------------------------------------------------
