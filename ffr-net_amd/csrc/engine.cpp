@@ -573,8 +573,8 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         bool pooled = false;
         const int tiles = ((ho + 3) / 4) * ((wo + 3) / 4);
         static const bool se_fuse = !(getenv("FFR_SE_FUSE") && atoi(getenv("FFR_SE_FUSE")) == 0);
-        // (beyond 64 tiles per image k_se_fc would spend more on adding partials than the separate pooling pass costs)
-        if (se_fuse && b.stride == 1 && tiles <= 64 && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
+        static const int se_maxtiles = getenv("FFR_SE_MAXTILES") ? atoi(getenv("FFR_SE_MAXTILES")) : 256;
+        if (se_fuse && b.stride == 1 && tiles <= se_maxtiles && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
         if (chained) c2.wino_stage = 2;
