@@ -76,11 +76,30 @@ def self_launch(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+    # a rank that dies must not leave the others waiting at the rendezvous (or in a collective) until a timeout: the
+    # first non-zero exit ends the job
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                rc = rc or r
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(out).decode())
     sys.stdout.flush()
     return rc
 
@@ -286,10 +305,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get('FFR_BENCH_DIST_TIMEOUT', '600')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local), timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     dev = torch.device('cuda', local)
     if args.workload == 'train':
         return train_workload(args, world, rank, local, dist)
@@ -395,6 +416,13 @@ def main():
                 'launches_per_step': dom['launches'] // nprof,
                 'avg_launch_us': round(dom['ms'] * 1e3 / max(1, dom['launches']), 2),
                 'gflop_executed_per_launch': round(dom['flops_executed'] / max(1, dom['launches']) / 1e9, 3),
+                # what the kernel is co-limited by: operand fragments streamed L2 -> registers; a 32x64 tile
+                # per xi and 8-channel chunk moves (32 + 64) * 8 * 4 bytes for 2 * 32 * 64 * 8 flops
+                'operand_stream': {'bytes_per_flop': 0.09375,
+                                   'tb_per_s': round(dom_tf * 0.09375, 2),
+                                   'bytes_per_clk_per_cu': round(dom_tf * 1e12 * 0.09375 / (256 * clock * 1e9), 1),
+                                   'note': 'V and U fragments of k_wino_fused, L2 (U) / Infinity Cache or L2 (V) -> VGPRs; '
+                                           'averaged over the launch incl. its transform and epilogue phases (K loop alone: 21 B/clk/CU)'},
                 'peak_measured': {'tflops': round(peak_meas, 1), 'shader_clock_ghz': round(clock, 3),
                                   'frac_of_measured': round(dom_tf / peak_meas, 4),
                                   'how': 'ffr_probe_mfma_peak: register-resident v_mfma_f32_32x32x2_f32 loop on every CU of '

@@ -45,9 +45,14 @@ if __name__ == '__main__':
     procs = [ctx.Process(target=worker, args=(r, 2, 29533, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(60)
+    try:
+        res = sorted(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:         # a rank that failed must not leave its peer waiting in a collective
+            if p.is_alive():
+                p.terminate()
     print('losses differ (different batches):', res[0][1] != res[1][1])
     print('parameters identical after the step:', res[0][2:] == res[1][2:])
     assert res[0][1] != res[1][1] and res[0][2:] == res[1][2:]
