@@ -506,3 +506,18 @@ def test_bench_and_trainer_two_ranks_on_one_gpu():
     out = _Sub.run([sys.executable, os.path.join(root, 'tools', 'ddp_two_ranks_one_gpu.py')], cwd=root, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_runs_the_product_collectives():
+    """RCCL itself (backend nccl), as far as one GPU allows: one rank, the product's collectives on the product's
+    buffers (tools/rccl_one_rank.py): embeddings all-gather, bucketed gradient all-reduce on the second stream,
+    parameter broadcast; every collective must be the identity."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
