@@ -309,6 +309,43 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         const long long block_tiles = ((T + 31) / 32) * (L.cout_pad / 64);
         const bool want_fused = c.wino_mode == 1 || (c.wino_mode < 0 && block_tiles >= min_blocks);
         if (fused_on && want_fused && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
+            // The launch runs in rounds of one block tile per CU, all of the same duration: a last round with few block
+            // tiles leaves most of the chip idle for a whole block time (784 block tiles of a 128 -> 128 layer at 28x28 =
+            // 3.06 rounds took 4: 245 us where 3 rounds are 178).  When the last round would be less than a quarter full,
+            // the images whose block tiles fill whole rounds run here and the remaining few images (2 % of the batch) on the
+            // transform-kernel + batched-GEMM path, whose small tiles spread over every CU.  FFR_WF_TAILSPLIT=0: off.
+            static const bool tail_split = !(getenv("FFR_WF_TAILSPLIT") && atoi(getenv("FFR_WF_TAILSPLIT")) == 0);
+            const long long full = block_tiles / h->num_cus * h->num_cus, rem = block_tiles - full;
+            if (tail_split && c.wino_mode < 0 && full > 0 && rem > 0 && rem * 4 <= h->num_cus && !getenv("FFR_WF_TRACE")) {
+                const int tiles_img = th * tw, nbn = L.cout_pad / 64;
+                // (leaving 8..64 CUs without a block tile in the last round for the remainder's kernels did not help: 16.78 ms
+                // per forward with none, 16.79 / 16.81 / 16.83 / 17.04 with 8 / 16 / 32 / 64)
+                const int n_main = (int)((full / nbn) * 32 / tiles_img);       // images whose tiles fit into full / nbn tile groups
+                const size_t rem_floats = (size_t)36 * (c.N - n_main) * tiles_img * (L.cin_pad > L.cout_pad ? L.cin_pad : L.cout_pad);
+                if (n_main >= 1 && n_main < c.N && rem_floats <= c.wino_cap) {
+                    ConvCall c1 = c, c2 = c;
+                    c1.N = n_main; c1.wino_mode = 1;
+                    c2.N = c.N - n_main; c2.wino_mode = 2;
+                    const size_t px = (size_t)n_main * c.H * c.W;
+                    c2.x = c.x + px * c.in_pitch;
+                    c2.out = c.out + px * c.out_pitch;
+                    if (c.resid) c2.resid = c.resid + px * c.res_pitch;
+                    if (c.tile_sums) c2.tile_sums = c.tile_sums + (size_t)n_main * tiles_img * L.cout_pad;
+                    // the remainder needs none of the main launch's buffers when that transforms its own input (phased): it
+                    // runs on the second stream, its short blocks slot in between the rounds of the main launch
+                    if (phased && h->side) {
+                        HIPCK(h, hipEventRecord(h->ev_fork, st));
+                        HIPCK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+                        RC(run_conv(h, L, c2, h->side));
+                        HIPCK(h, hipEventRecord(h->ev_join, h->side));
+                        RC(run_conv(h, L, c1, st));
+                        HIPCK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+                        return FFR_OK;
+                    }
+                    RC(run_conv(h, L, c1, st));
+                    return run_conv(h, L, c2, st);
+                }
+            }
             if (c.took_wino) *c.took_wino = true;
             if (!phased) {
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
@@ -735,6 +772,7 @@ int ffr_create(ffr_handle** out, int device) {
                     prop.gcnArchName);
     ffr_handle* h = new ffr_handle();
     h->device = device;
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     void* z = nullptr;
     if (hipMalloc(&z, 131072) != hipSuccess) { delete h; return fail(nullptr, FFR_ERR_NOMEM, "hipMalloc failed"); }
     hipMemset(z, 0, 131072);
@@ -742,6 +780,9 @@ int ffr_create(ffr_handle** out, int device) {
     hipError_t e = igemm_init();
     if (e == hipSuccess) e = gemm_stream_init();
     if (e == hipSuccess) e = wino_fused_init();
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         hipFree(z); delete h;
         return fail(nullptr, FFR_ERR_HIP, "igemm_init: %s", hipGetErrorString(e));
@@ -757,6 +798,9 @@ void ffr_destroy(ffr_handle* h) {
     train_free(h);
     free_list(h->enc_allocs);
     free_list(h->rec_allocs);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     if (h->arena) hipFree(h->arena);
     if (h->tickets) hipFree(h->tickets);
     if (h->zero) hipFree(h->zero);
@@ -1095,7 +1139,7 @@ int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
         float ms = 0.f;
         HIPCK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
         out[r.kc].launches += 1;
-        out[r.kc].ms += ms;
+        if (!r.side) out[r.kc].ms += ms;     // second-stream work overlaps a main-stream launch that is already counted
         out[r.kc].flops += r.flops;
         out[r.kc].bytes += r.bytes;
         out[r.kc].flops_executed += r.fexec;

@@ -44,12 +44,16 @@ struct ProfRec {
     hipEvent_t e0, e1;
     int kc;
     double flops, bytes, fexec;
+    bool side;          // enqueued on the handle's second stream: runs beside a launch of the main stream
 };
 
 }  // namespace ffr_eng
 
 struct ffr_handle {
     int device = 0;
+    int num_cus = 256;       // multiProcessorCount of the device
+    hipStream_t side = nullptr;          // second stream: the few images split off a fused Winograd launch run beside it
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     float* zero = nullptr;   // 128 KiB zero page (source of zero-padded taps, >= any cin_pad)
     // weights
@@ -126,6 +130,7 @@ struct Scope {
             return e;
         };
         r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes; r.fexec = fexec < 0 ? flops : fexec;
+        r.side = h->side && st == h->side;
         hipEventRecord(r.e0, st);
     }
     ~Scope() {

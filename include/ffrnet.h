@@ -118,7 +118,10 @@ int    ffr_reserve(ffr_handle* h, int N, int H, int W);
  * Classes: see FFR_KC_*.  ffr_profile_read() synchronises the recorded events and
  * returns, per class, the number of launches, the summed device time in ms and the
  * algorithmic FLOPs (2*MACs), executed FLOPs and bytes (compulsory in+out+weights) of
- * those launches, then clears the log.                                                              */
+ * those launches, then clears the log.  Launches that the engine puts on its second
+ * stream (the few images split off a fused Winograd launch, which run beside it) count
+ * with their launches, FLOPs and bytes but not with their time: it overlaps a launch of
+ * the main stream that is already counted.                                              */
 enum {
     FFR_KC_CONV_IGEMM = 0,  /* fp32-MFMA implicit-GEMM conv / FC (the dominant kernel) */
     FFR_KC_STEM = 1,
