@@ -252,6 +252,20 @@ def test_batch_independence_full_size(engine, state_dicts):
     assert torch.equal(f_new2, f_new) and torch.equal(f2, f)
 
 
+@pytest.mark.parametrize('B', [200, 300])
+def test_batch_independence_odd_batches(engine, state_dicts, B):
+    """Batches that are not a power of two: the fused Winograd launches split off a different number of images for
+    the transform-kernel path (whole rounds of block tiles), tile groups straddle images, the last
+    tile group is partly empty.  Every row must match the same image embedded in a batch of 8."""
+    x = synth.synth_images(B, seed=4300 + B).cuda()
+    f_new, f = engine.embed(x)
+    f_new, f = f_new.clone(), f.clone()
+    assert torch.isfinite(f_new).all() and torch.isfinite(f).all()
+    for i in range(0, B, 8):
+        g_new, g = engine.embed(x[i:i + 8].contiguous())
+        assert rel(f_new[i:i + 8], g_new) < 2e-5 and rel(f[i:i + 8], g) < 2e-5, i
+
+
 def test_encoder_forward_and_trunk_112x96_full_size(engine, state_dicts):
     """ffr_encoder_forward (NCHW featmap out, BASELINE configs[1]) and the 112x96 trunk at batch 256: every image
     equals its batch-8 run; a subset is held to the oracle."""
