@@ -784,8 +784,11 @@ int ffr_create(ffr_handle** out, int device) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
+        if (h->ev_fork) hipEventDestroy(h->ev_fork);
+        if (h->ev_join) hipEventDestroy(h->ev_join);
+        if (h->side) hipStreamDestroy(h->side);
         hipFree(z); delete h;
-        return fail(nullptr, FFR_ERR_HIP, "igemm_init: %s", hipGetErrorString(e));
+        return fail(nullptr, FFR_ERR_HIP, "ffr_create: %s", hipGetErrorString(e));
     }
     *out = h;
     return FFR_OK;
