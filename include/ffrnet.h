@@ -14,7 +14,10 @@
  *    fp32; 4-D tensors at the boundary are NCHW contiguous (the reference's layout),
  *    the NHWC layout used inside never leaves the library;
  *  - launches are asynchronous on the hipStream_t passed as `void* stream`
- *    (NULL = the default stream); no hidden device synchronisation;
+ *    (NULL = the default stream); no hidden device synchronisation.  A call may fork
+ *    part of its work onto a second stream the handle owns and joins it back with events
+ *    before it returns: for the caller everything is ordered on `stream`, and a call
+ *    captured into a hipGraph on `stream` stays one graph;
  *  - one handle per device; a handle is not thread safe.
  */
 #ifndef FFRNET_H
