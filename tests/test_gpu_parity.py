@@ -535,3 +535,28 @@ def test_rccl_one_rank_runs_the_product_collectives():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], cwd=root, env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_experiment_knobs_keep_parity(tmp_path):
+    """The A/B knobs of DESIGN.md 3.3 select other kernels / mappings for the same arithmetic: every setting must
+    reproduce the default path's embeddings (batch 96: fused Winograd launches with and without a split-off remainder,
+    both block maps, SE squeeze from tile sums or from its own pass, the round-1 transform kernels, no Winograd)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, 'tools', 'knob_embed.py')
+
+    def run(name, **knobs):
+        path = str(tmp_path / (name + '.pt'))
+        env = dict(os.environ, **knobs)
+        out = subprocess.run([sys.executable, tool, path, '96'], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and 'OK' in out.stdout, (name, out.stderr[-2000:])
+        return torch.load(path)
+
+    ref = run('default')
+    for name, knobs in (('mapv0', {'FFR_WF_MAPV': '0'}), ('notailsplit', {'FFR_WF_TAILSPLIT': '0'}),
+                        ('sepool', {'FFR_SE_MAXTILES': '0'}), ('unfused', {'FFR_WINO_FUSED': '0'}),
+                        ('phased256', {'FFR_WF_PHASED_MAXK': '256'}), ('direct', {'FFR_WINO': '0'})):
+        got = run(name, **knobs)
+        for k in ('f_new', 'f'):
+            assert rel(got[k], ref[k]) < 2e-5, (name, k, rel(got[k], ref[k]))

@@ -1,0 +1,18 @@
+"""Embed one synthetic batch and save (f_new, f) -- run under different FFR_* experiment knobs by
+tests/test_gpu_parity.py::test_experiment_knobs_keep_parity (the knobs are read once per process)."""
+import json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ffrnet_amd  # noqa: E402
+from ffrnet_amd import synth  # noqa: E402
+
+out, B = sys.argv[1], int(sys.argv[2])
+specs = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g0_state_dict_keys.json')))
+eng = ffrnet_amd.Engine(0)
+eng.load_encoder(synth.synth_state_dict(specs['encoder']))
+eng.load_recnet(synth.synth_state_dict(specs['recnet']))
+f_new, f = eng.embed(synth.synth_images(B, seed=77).cuda())
+torch.cuda.synchronize()
+torch.save({'f_new': f_new.cpu(), 'f': f.cpu()}, out)
+print('OK')
