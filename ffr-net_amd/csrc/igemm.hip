@@ -310,13 +310,26 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
             for (int p = 0; p < BM / RPP; ++p) {
                 const int ml = p * RPP + erow;
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                for (int bb = b_lo; bb <= b_hi; ++bb) {
-                    if (bb == (int)blockIdx.x) {
-                        sum += *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
-                    } else {
-                        const int slot = ((long long)bb * G / P * a.granule > tb) ? 0 : 1;
-                        sum += *reinterpret_cast<const f32x4*>(a.partial + ((size_t)bb * 2 + slot) * (BM * BN) + ml * BN + ecol);
+                // eight slabs in flight at a time, added in block order (a tile of the FC is cut into 32 segments: one load per
+                // add left the last arriver waiting a memory latency 128 times, half of that launch's 123 us)
+                for (int bb = b_lo; bb <= b_hi; bb += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int bk = bb + k;
+                        v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (bk <= b_hi) {
+                            if (bk == (int)blockIdx.x) {
+                                v[k] = *reinterpret_cast<const f32x4*>(sC + ml * LDC + ecol);
+                            } else {
+                                const int slot = ((long long)bk * G / P * a.granule > tb) ? 0 : 1;
+                                v[k] = *reinterpret_cast<const f32x4*>(a.partial + ((size_t)bk * 2 + slot) * (BM * BN) + ml * BN + ecol);
+                            }
+                        }
                     }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (bb + k <= b_hi) sum += v[k];
                 }
                 *reinterpret_cast<f32x4*>(sC + ml * LDC + ecol) = sum;   // same thread re-reads it below
             }
