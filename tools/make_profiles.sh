@@ -13,6 +13,7 @@ python3 bench.py --pairs-per-step 512 --no-cpu-baseline --no-secondary > $O/r02_
 FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --pairs-per-step 512 --no-roofline --no-cpu-baseline > $O/r02_bench_selflaunch_2ranks_one_device.json 2>> $O/bench.err
 python3 tools/bench_train.py --cpu-baseline > $O/r02_train_step.json 2>> $O/bench.err
 FFR_WF_TRACE=1 python3 tools/wf_trace.py 2>&1 | grep "wf trace" > $O/r02_wino_fused_phase_trace.txt
+FFR_IGEMM_TRACE=1 python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > $O/r02_igemm_trace.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/r02_bench_under_rocprof.json 2>/dev/null
 cp $O/prof/p_kernel_stats.csv $O/r02_bench_kernel_stats.csv
