@@ -233,12 +233,46 @@ def timed_events(fn, warm, reps):
     return [a.elapsed_time(b) for a, b in evs]
 
 
+def lfw_protocol_line(eng, dev):
+    """configs[3] end to end on one GPU: 6000 pairs (12000 images resident in HBM, pair batches of 512) through the
+    product harness -- embed, ffr_cosine_scores, ffr_lfw_fold_accuracy for f_new and f -- wall clock incl. the
+    device->host copies of the results."""
+    import torch
+    from ffrnet_amd import lfw
+    n, bs = 6000, 512
+    g = torch.Generator(device=dev).manual_seed(9)
+    loader = []
+    for s0 in range(0, n, bs):
+        m = min(bs, n - s0)
+        a = torch.rand((m, 3, 112, 112), device=dev, generator=g) * 2 - 1
+        b = torch.rand((m, 3, 112, 112), device=dev, generator=g) * 2 - 1
+        lab = ((torch.arange(s0, s0 + m) % 600) < 300).long()
+        mix = lab.view(-1, 1, 1, 1).to(dev).float() * 0.7
+        loader.append(dict(img1=a, img2=mix * a + (1 - mix) * b, label=lab, idx=torch.arange(s0, s0 + m)))
+    lfw.get_avg_accuracy(eng.embed, loader[:1], n_folds=2)            # warm-up (arena for 1024 images)
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        acc_new, acc = lfw.get_avg_accuracy(eng.embed, loader)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return {'workload': 'configs[3] on 1 GPU: LFW protocol, 6000 synthetic pairs in pair batches of 512 '
+                        '(12000 images resident in HBM) -> embeddings -> cosine scores -> 10-fold threshold protocol '
+                        'for f_new and f, all on the device (ffrnet_amd.lfw.get_avg_accuracy, default path)',
+            'value': round(n / best, 1), 'unit': 'pairs/s', 'seconds': round(best, 4),
+            'embeddings_per_s': round(2 * n / best, 1), 'acc_new': acc_new, 'acc': acc,
+            'note': 'random pairs generated on the device: the accuracies are not comparable with golden G9 '
+                    '(tests/test_gpu_parity.py::test_lfw_protocol_6000_pairs_matches_reference holds that)'}
+
+
 def train_workload(args, world, rank, local, dist):
     """Secondary workload (SURVEY 8 row N3 / BASELINE configs[4]): whole training iterations through NativeTrainer."""
     import torch
     import ffrnet_amd
     from ffrnet_amd import synth
     dev = torch.device('cuda', local)
+    torch.set_num_threads(max(1, host_cores() // world))
     spec_e, spec_r = state_dict_specs()
     eng = ffrnet_amd.Engine(local)
     eng.load_encoder(synth.synth_state_dict(spec_e))
@@ -315,6 +349,7 @@ def main():
     if args.workload == 'train':
         return train_workload(args, world, rank, local, dist)
 
+    torch.set_num_threads(max(1, host_cores() // world))     # N ranks synthesise and pack weights side by side
     spec_e, spec_r = state_dict_specs()
     sd_e = synth.synth_state_dict(spec_e)
     sd_r = synth.synth_state_dict(spec_r)
@@ -343,19 +378,26 @@ def main():
         sys.exit(3)
 
     x = synth.synth_images(B, seed=124 + rank).to(dev)
-    f_new = torch.empty((B, 512), device=dev)
-    f = torch.empty((B, 512), device=dev)
-    g_new = torch.empty((world * B, 512), device=dev) if world > 1 else f_new
-    g_old = torch.empty((world * B, 512), device=dev) if world > 1 else f
+    # the engine writes f_new and f into the two halves of ONE packed buffer, so the exchange is ONE collective
+    # (ffrnet_amd/lfw.py packs the same way): [2][B][512] per rank -> [world][2][B][512]
+    pack = torch.empty((2, B, 512), device=dev)
+    f_new, f = pack[0], pack[1]
+    gathered = torch.empty((world, 2, B, 512), device=dev) if world > 1 else pack.view(1, 2, B, 512)
+    coll_ev = []
 
-    def step():
+    def step(timed=False):
         eng.embed(x, out=(f_new, f))
         if world > 1:
-            dist.all_gather_into_tensor(g_new, f_new)
-            dist.all_gather_into_tensor(g_old, f)
-        # image 2i / 2i+1 of the gathered batch form verification pair i
-        a, b = g_new.view(-1, 2, 512)[:, 0], g_new.view(-1, 2, 512)[:, 1]
-        return eng.cosine_scores(a.contiguous(), b.contiguous())
+            if timed:
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+            dist.all_gather_into_tensor(gathered.view(world * 2 * B, 512), pack.view(2 * B, 512))
+            if timed:
+                c1.record()
+                coll_ev.append((c0, c1))
+        # image 2i / 2i+1 of a rank's batch form a verification pair: [world * B/2] pairs per step
+        pr = gathered[:, 0].reshape(-1, 2, 512)
+        return eng.cosine_scores(pr[:, 0].contiguous(), pr[:, 1].contiguous())
 
     def fence():
         if world > 1:
@@ -370,16 +412,30 @@ def main():
     for _ in range(args.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        scores = step()
+        scores = step(timed=True)
         e1.record()
         evs.append((e0, e1))
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    assert torch.isfinite(scores).all()
+        # what every rank measured (its own wall clock per step, its step and collective hipEvent medians), so that a
+        # scaling loss can be attributed: a slow rank, the collective, or the launch path
+        mine = torch.tensor([dt_local / args.steps * 1e3,
+                             percentiles([a.elapsed_time(b) for a, b in evs])['median'],
+                             percentiles([a.elapsed_time(b) for a, b in coll_ev])['median']], device=dev, dtype=torch.float64)
+        allr = torch.empty((world, 3), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        dt = allr[:, 0].max().item() * args.steps / 1e3                      # MAX over ranks
+        per_rank = {'wall_ms_per_step': [round(v, 3) for v in allr[:, 0].tolist()],
+                    'step_ms_hipevents_median': [round(v, 3) for v in allr[:, 1].tolist()],
+                    'all_gather_ms_hipevents_median': [round(v, 4) for v in allr[:, 2].tolist()],
+                    'all_gather_bytes_per_rank': 2 * B * 512 * 4,
+                    'note': 'the all-gather event pair also waits for the slowest rank to arrive'}
+        # the exchange put every rank's rows where the scoring reads them: this rank's slice is its own output
+        assert torch.equal(gathered[rank], pack), 'all-gather: rank %d does not find its own embeddings' % rank
+    assert torch.isfinite(scores).all() and scores.numel() == world * B // 2
     step_ms = percentiles([a.elapsed_time(b) for a, b in evs])
     value = world * B * args.steps / dt
 
@@ -458,6 +514,7 @@ def main():
                          'lfw/gen_lfw112x96.py:16 vs model_ir_se50.py:124), batch %d -> featmap [512,7,6]' % B,
              'value': round(B / ms96['median'] * 1e3, 1), 'unit': 'images/s', 'ms': ms96,
              'effective_tflops_algorithmic': round(B * GFLOP_TRUNK_96 / ms96['median'], 2)}]
+        secondary.append(lfw_protocol_line(eng, dev))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -478,7 +535,7 @@ def main():
                                          'reference: BASELINE.md)',
                           'batch_per_gpu': B, 'global_batch': world * B, 'gflop_per_image': GFLOP_PER_IMAGE,
                           'parallelism': 'image-sharded x%d, RCCL all-gather of embeddings' % world},
-               'step_ms_hipevents': step_ms,
+               'step_ms_hipevents': step_ms, 'per_rank': per_rank,
                'parity_checked': {'max_rel_err_vs_reference_golden_G1': parity, 'tolerance': PARITY_TOL},
                'roofline': roof, 'cpu_baseline': cpu, 'secondary': secondary}
         print(json.dumps(out))

@@ -105,7 +105,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     RC(upload(h, owner, bias, &L->bias));
     L->wu = nullptr;
     L->wuc = nullptr;
-    static const int wino_min_cin = getenv("FFR_WINO_MINCIN") ? atoi(getenv("FFR_WINO_MINCIN")) : 64;
+    const int wino_min_cin = h->opt.wino_mincin;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
         // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
         static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -177,8 +177,7 @@ void block_table(int cin[24], int depth[24], int stride[24]) {
 //    efficiency measured on the MI355X: 128x128 > 128x64 > 64x64, profiles/r01_conv_sweep*);
 //  * small problems: 64x64 tiles; whole tiles per block when they fill 160..1024 blocks
 //    (nothing is cut), else stream-K with at least `min_units` K-tiles per block.
-void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, int* tile, int* nblocks, int* granule) {
-    static const int min_units = getenv("FFR_SK_MINUNITS") ? atoi(getenv("FFR_SK_MINUNITS")) : 18;
+void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, int min_units, int* tile, int* nblocks, int* granule) {
     auto ntiles = [&](int t) {
         int bm, bn;
         igemm_tile_shape(t, &bm, &bn);
@@ -226,7 +225,7 @@ void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, i
 // plan + launch one (possibly batched) implicit-GEMM described by `a` (M, nkt, cout_pad, nbatch set)
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st) {
     int tile, nblocks;
-    plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, c.tile, &tile, &nblocks, &a.granule);
+    plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, c.tile, h->opt.sk_minunits, &tile, &nblocks, &a.granule);
     int bm, bn;
     igemm_tile_shape(tile, &bm, &bn);
     a.mtiles = (a.M + bm - 1) / bm;
@@ -237,8 +236,8 @@ int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, doubl
     a.partial = c.partial;
     a.tickets = c.tickets;
     if ((size_t)a.nbatch * a.mtiles * a.ntiles > c.tickets_cap) return fail(h, FFR_ERR_NOMEM, "stream-K ticket array too small");
-    static const bool trace_on = getenv("FFR_IGEMM_TRACE") != nullptr;
-    if (trace_on) {   // diagnostic: per-block clock sums, printed after a stream sync
+#ifdef FFR_TRACE
+    if (h->opt.igemm_trace) {   // diagnostic: per-block clock sums, printed after a stream sync
         unsigned long long* dbuf = nullptr;
         HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nblocks * 8 * sizeof(unsigned long long)));
         a.trace = dbuf;
@@ -264,7 +263,10 @@ int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, doubl
                         "loop %.0f (%.0f per K-tile) epilogue %.0f (first barrier at %.0f, C in LDS at %.0f) cyc | span %.1f us, starts within %.1f us, shader clock %.2f GHz\n",
                 tile, nblocks, units, a.nkt, segs / nblocks, acc[0] / segs, acc[1] / segs, acc[2] / segs,
                 acc[2] / ((double)units), acc[3] / segs, e1 / segs, e2 / segs, (double)(r1 - r0) / 100.0, (double)(smax - r0) / 100.0, ghz / nblocks);
-    } else {
+        return FFR_OK;
+    }
+#endif
+    {
         const double fexec = 2.0 * a.nbatch * (double)a.mtiles * bm * (double)a.cout_pad * a.KK;
         Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes, fexec);
         HIPCK(h, launch_igemm(a, tile, nblocks, st));
@@ -290,41 +292,58 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     a.nbatch = 1;
     const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
     const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
-    static const bool wino_on = !(getenv("FFR_WINO") && atoi(getenv("FFR_WINO")) == 0);
+    const bool wino_on = h->opt.wino != 0;
     if (L.wu && c.winoV && c.tile == 0 && (c.wino_mode >= 1 || (c.wino_mode < 0 && wino_on))) {
         // Winograd F(4x4,3x3): input transform -> 36 batched GEMMs [T x cin] * [cin x cout] -> output transform
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
         const long long T = (long long)c.N * th * tw;
         // GEMM + output transform in one kernel (wino_fused.hip): M never exists in memory
-        static const bool fused_on = !(getenv("FFR_WINO_FUSED") && atoi(getenv("FFR_WINO_FUSED")) == 0);
+        const bool fused_on = h->opt.wino_fused != 0;
         // K <= 128: the fused kernel transforms its own input (V never exists in memory); larger K: separate transform
         // kernel (measured at batch 256: 17.99 / 18.04 / 18.78 ms per forward for a limit of 64 / 128 / 256, 18.67 without)
-        static const int phased_maxk = getenv("FFR_WF_PHASED_MAXK") ? atoi(getenv("FFR_WF_PHASED_MAXK")) : 128;
+        const int phased_maxk = h->opt.wf_phased_maxk;
         const double x_bytes = 4.0 * c.N * c.H * c.W * c.in_pitch;
         const bool phased = L.cin_pad <= phased_maxk && x_bytes <= 1073741824.0;
         // One block tile (32 tiles x 64 channels, all 36 xi) occupies a whole CU and cannot be cut: a launch with fewer
         // block tiles than CUs leaves matrix cores idle, where the batched-GEMM path balances K-tiles over every CU
         // (Conv4Space at batch 256: 32..128 block tiles, 1.07 ms fused vs 0.55 ms unfused).  wino_mode 1 forces fused.
-        static const long long min_blocks = getenv("FFR_WF_MINBLOCKS") ? atoll(getenv("FFR_WF_MINBLOCKS")) : 200;
-        const long long block_tiles = ((T + 31) / 32) * (L.cout_pad / 64);
-        const bool want_fused = c.wino_mode == 1 || (c.wino_mode < 0 && block_tiles >= min_blocks);
+        const long long min_blocks = h->opt.wf_minblocks;
+        const long long mbn = (T + 31) / 32;
+        const long long bt_full = mbn * (L.cout_pad / 64);
+        const bool tail_split = h->opt.wf_tailsplit != 0 && !h->opt.wf_trace;
+        // Second block shape, 32 tiles x 32 channels (half the accumulators and half the work per block, twice the blocks):
+        // for launches whose 32 x 64 block tiles cannot fill the chip (stage 4 / RecNet at 128 images: 128 block tiles) or
+        // fill their last round badly (128 -> 128 at 28x28 and 128 images: 392 = 1.53 rounds).  Not with the in-kernel input
+        // transform, which every block of a tile group would repeat.
+        auto fit = [&](long long bt) {          // share of the launch's rounds that carries work
+            const long long full = bt / h->num_cus * h->num_cus, rem = bt - full;
+            if (rem == 0 || (tail_split && c.wino_mode < 0 && full > 0 && rem * 4 <= h->num_cus)) return 1.0;
+            return (double)bt / (double)(full + h->num_cus);
+        };
+        bool half_n = c.wino_mode == 3;
+        if (c.wino_mode < 0 && h->opt.wf_halfblocks && !phased) {
+            if (bt_full < min_blocks) half_n = 2 * bt_full >= min_blocks;
+            else half_n = 0.92 * fit(2 * bt_full) > fit(bt_full);       // a half block costs ~8 % more per unit of work
+        }
+        const int nbn = L.cout_pad / (half_n ? 32 : 64);
+        const long long block_tiles = mbn * nbn;
+        const bool want_fused = c.wino_mode == 1 || c.wino_mode == 3 || (c.wino_mode < 0 && block_tiles >= min_blocks);
         if (fused_on && want_fused && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
             // The launch runs in rounds of one block tile per CU, all of the same duration: a last round with few block
             // tiles leaves most of the chip idle for a whole block time (784 block tiles of a 128 -> 128 layer at 28x28 =
             // 3.06 rounds took 4: 245 us where 3 rounds are 178).  When the last round would be less than a quarter full,
             // the images whose block tiles fill whole rounds run here and the remaining few images (2 % of the batch) on the
-            // transform-kernel + batched-GEMM path, whose small tiles spread over every CU.  FFR_WF_TAILSPLIT=0: off.
-            static const bool tail_split = !(getenv("FFR_WF_TAILSPLIT") && atoi(getenv("FFR_WF_TAILSPLIT")) == 0);
+            // transform-kernel + batched-GEMM path, whose small tiles spread over every CU.  Option wf_tailsplit = 0: off.
             const long long full = block_tiles / h->num_cus * h->num_cus, rem = block_tiles - full;
-            if (tail_split && c.wino_mode < 0 && full > 0 && rem > 0 && rem * 4 <= h->num_cus && !getenv("FFR_WF_TRACE")) {
-                const int tiles_img = th * tw, nbn = L.cout_pad / 64;
+            if (tail_split && c.wino_mode < 0 && full > 0 && rem > 0 && rem * 4 <= h->num_cus) {
+                const int tiles_img = th * tw;
                 // (leaving 8..64 CUs without a block tile in the last round for the remainder's kernels did not help: 16.78 ms
                 // per forward with none, 16.79 / 16.81 / 16.83 / 17.04 with 8 / 16 / 32 / 64)
                 const int n_main = (int)((full / nbn) * 32 / tiles_img);       // images whose tiles fit into full / nbn tile groups
                 const size_t rem_floats = (size_t)36 * (c.N - n_main) * tiles_img * (L.cin_pad > L.cout_pad ? L.cin_pad : L.cout_pad);
                 if (n_main >= 1 && n_main < c.N && rem_floats <= c.wino_cap) {
                     ConvCall c1 = c, c2 = c;
-                    c1.N = n_main; c1.wino_mode = 1;
+                    c1.N = n_main; c1.wino_mode = half_n ? 3 : 1;
                     c2.N = c.N - n_main; c2.wino_mode = 2;
                     const size_t px = (size_t)n_main * c.H * c.W;
                     c2.x = c.x + px * c.in_pitch;
@@ -356,16 +375,16 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // block -> tile mapping: the channel groups of a tile group next to each other on ONE XCD (V is fetched into that
             // L2 once instead of once per channel group: 59.5 -> 45.7 GB fetched + written per forward, 17.53 -> 17.32 ms at
             // batch 256); FFR_WF_MAPV=0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
-            static const bool map_v = !(getenv("FFR_WF_MAPV") && atoi(getenv("FFR_WF_MAPV")) == 0);
-            f.map_v = map_v ? 1 : 0;
+            f.map_v = h->opt.wf_mapv ? 1 : 0;
+            f.half_n = half_n ? 1 : 0;
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
             f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
             f.cout_pad = L.cout_pad; f.cout_store = c.cout_store; f.out_pitch = c.out_pitch; f.out_coff = c.out_coff;
             f.res_pitch = c.res_pitch; f.border_bias = L.border; f.flags = c.flags;
             const double fexec = 2.0 * 36.0 * (double)((T + 31) / 32 * 32) * (double)L.cout_pad * L.cin_pad;
-            static const bool wf_trace = getenv("FFR_WF_TRACE") != nullptr;
-            if (wf_trace) {     // diagnostics: per-block phase stamps, printed after a stream sync
+#ifdef FFR_TRACE
+            if (h->opt.wf_trace) {     // diagnostics: per-block phase stamps, printed after a stream sync
                 const int nb = wino_fused_blocks(f);
                 unsigned long long* dbuf = nullptr;
                 HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nb * 40 * sizeof(unsigned long long)));
@@ -401,6 +420,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
                 return FFR_OK;
             }
+#endif
             Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec);
             HIPCK(h, launch_wino_fused(f, st));
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
@@ -409,7 +429,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         if ((size_t)36 * T * L.cin_pad <= c.wino_cap && (size_t)36 * T * L.cout_pad <= c.wino_cap && T < 0x7fffffffLL) {
             // sub-batches: V and M of one slice (36 * tiles * channels * 4 B each) should stay in the
             // 256 MiB Infinity Cache between the transform that writes them and the kernel that reads them
-            static const long long slice_mb = getenv("FFR_WINO_SLICE_MB") ? atoll(getenv("FFR_WINO_SLICE_MB")) : 0;
+            const long long slice_mb = h->opt.wino_slice_mb;
             int nslice = 1;
             if (slice_mb > 0 && c.wino_stage == 0) {
                 const double mb = 36.0 * T * (L.cin_pad + L.cout_pad) * 4.0 / 1048576.0;
@@ -429,7 +449,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 }
                 // 36 GEMMs [Ts x cin] * [cin x cout] in one persistent launch with a continuous K-tile stream;
                 // tile shape: fewest rounds of whole tiles over the resident blocks, weighted by loop efficiency
-                static const bool use_stream = !(getenv("FFR_GEMM_STREAM") && atoi(getenv("FFR_GEMM_STREAM")) == 0);
+                const bool use_stream = h->opt.gemm_stream != 0;
                 if (use_stream) {
                     int gtile = IGEMM_TILE_128x64, gblocks = 768;
                     double best = 1e300;
@@ -447,7 +467,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                         const double cost = rounds * bm * bn * share / (tt == IGEMM_TILE_128x128 ? 1.0 : 0.92);
                         if (cost < best) { best = cost; gtile = tt; gblocks = (int)p; }
                     }
-                    static const int force_gs = getenv("FFR_GS_TILE") ? atoi(getenv("FFR_GS_TILE")) : 0;
+                    const int force_gs = h->opt.gs_tile;
                     if ((force_gs == IGEMM_TILE_128x128 && L.cout_pad % 128 == 0) || force_gs == IGEMM_TILE_128x64) {
                         gtile = force_gs;
                         int bm, bn;
@@ -493,7 +513,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
 
 // ---- workspace ---------------------------------------------------------------------------
 
-Work layout(char* base, int N, int H, int W) {
+Work layout(const Options& opt, char* base, int N, int H, int W) {
     Arena a(base, 0);
     Work w{};
     const size_t S0 = (size_t)N * H * W * 64;
@@ -512,7 +532,7 @@ Work layout(char* base, int N, int H, int W) {
     {
         auto tiles = [&](int div) { return (size_t)N * ((H / div + 3) / 4) * ((W / div + 3) / 4); };
         size_t cap = 36 * tiles(2) * 128;                                   // 56x56, 64 -> 128 channels
-        static const bool wino_112 = !(getenv("FFR_WINO_112") && atoi(getenv("FFR_WINO_112")) == 0);
+        const bool wino_112 = opt.wino_112 != 0;
         if (wino_112 && 36 * tiles(1) * 64 > cap) cap = 36 * tiles(1) * 64;   // 112x112, 64 -> 64 (first bottleneck)
         if (36 * tiles(4) * 256 > cap) cap = 36 * tiles(4) * 256;           // 28x28, 128 -> 256
         if (36 * tiles(8) * 512 > cap) cap = 36 * tiles(8) * 512;           // 14x14, 256 -> 512
@@ -541,7 +561,7 @@ Work layout(char* base, int N, int H, int W) {
 }
 
 int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
-    const size_t need = layout(nullptr, N, H, W).total;
+    const size_t need = layout(h->opt, nullptr, N, H, W).total;
     if (need > h->arena_bytes) {
         if (h->arena) { hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; ++h->generation; }
         void* p = nullptr;
@@ -560,7 +580,7 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
         h->tickets = (int*)p;
         h->tickets_cap = need_t;
     }
-    *w = layout(h->arena, N, H, W);
+    *w = layout(h->opt, h->arena, N, H, W);
     w->tickets = h->tickets;
     w->tickets_cap = h->tickets_cap;
     return FFR_OK;
@@ -587,10 +607,10 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         c1.out = w.t1; c1.out_pitch = b.depth; c1.cout_store = b.depth;
         c1.partial = w.partial; c1.partial_cap = w.partial_cap; c1.tickets = w.tickets; c1.tickets_cap = w.tickets_cap; c1.winoV = w.winoV; c1.winoM = w.winoM; c1.wino_cap = w.wino_cap;
         // conv1 -> conv2 without the activation round trip when both run as Winograd on a map of <= 4x4 tiles
-        static const bool oi_fuse = !(getenv("FFR_WINO_OI") && atoi(getenv("FFR_WINO_OI")) == 0);
+        const bool oi_fuse = h->opt.wino_oi != 0;
         const long long Tt = (long long)N * ((ch + 3) / 4) * ((cw + 3) / 4);
         bool chained = false;
-        static const bool fused_on = !(getenv("FFR_WINO_FUSED") && atoi(getenv("FFR_WINO_FUSED")) == 0);
+        const bool fused_on = h->opt.wino_fused != 0;
         if (!fused_on && oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
             wino_out_in_supported(ch, cw, b.c1.cout_pad) && (size_t)36 * Tt * b.c1.cout_pad <= w.wino_cap &&
             (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
@@ -609,8 +629,8 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         // ([N][tiles][C], the layout k_se_fc reads); the direct path (stride 2, 64 channels) pools separately
         bool pooled = false;
         const int tiles = ((ho + 3) / 4) * ((wo + 3) / 4);
-        static const bool se_fuse = !(getenv("FFR_SE_FUSE") && atoi(getenv("FFR_SE_FUSE")) == 0);
-        static const int se_maxtiles = getenv("FFR_SE_MAXTILES") ? atoi(getenv("FFR_SE_MAXTILES")) : 256;
+        const bool se_fuse = h->opt.se_fuse != 0;
+        const int se_maxtiles = h->opt.se_maxtiles;
         if (se_fuse && b.stride == 1 && tiles <= se_maxtiles && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
@@ -743,7 +763,8 @@ int check_fwd(ffr_handle* h, bool need_enc, bool need_rec, int N) {
     if (need_enc && !h->enc_loaded) return fail(h, FFR_ERR_STATE, "encoder weights are not loaded");
     if (need_rec && !h->rec_loaded) return fail(h, FFR_ERR_STATE, "recnet weights are not loaded");
     int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    if (hipGetDevice(&cur) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipGetDevice failed");
+    if (cur != h->device) return fail(h, FFR_ERR_HIP, "current device %d != handle device %d (entry point without FFR_DEVICE_SCOPE?)", cur, h->device);
     return FFR_OK;
 }
 
@@ -1007,9 +1028,8 @@ int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n) {
 }
 
 size_t ffr_workspace_bytes(const ffr_handle* h, int N, int H, int W) {
-    (void)h;
     if (N <= 0 || H <= 0 || W <= 0) return 0;
-    return layout(nullptr, N, H, W).total;
+    return layout(h ? h->opt : Options(), nullptr, N, H, W).total;
 }
 
 int ffr_reserve(ffr_handle* h, int N, int H, int W) {
@@ -1098,30 +1118,77 @@ int ffr_lfw_fold_accuracy(ffr_handle* h, const float* score, const int32_t* labe
 
 unsigned long long ffr_generation(const ffr_handle* h) { return h ? h->generation : 0; }
 
+namespace {
+struct OptEntry { const char* name; int ffr_eng::Options::*i; long long ffr_eng::Options::*l; long long lo, hi; };
+const OptEntry OPTIONS[] = {
+    {"wino", &Options::wino, nullptr, 0, 1}, {"wino_mincin", &Options::wino_mincin, nullptr, 0, 1 << 20},
+    {"wino_112", &Options::wino_112, nullptr, 0, 1}, {"wino_fused", &Options::wino_fused, nullptr, 0, 1},
+    {"wf_phased_maxk", &Options::wf_phased_maxk, nullptr, 0, 1 << 20}, {"wf_minblocks", nullptr, &Options::wf_minblocks, 0, 1LL << 40},
+    {"wf_halfblocks", &Options::wf_halfblocks, nullptr, 0, 1},
+    {"se_maxtiles", &Options::se_maxtiles, nullptr, 0, 1 << 20}, {"wf_tailsplit", &Options::wf_tailsplit, nullptr, 0, 1},
+    {"wf_mapv", &Options::wf_mapv, nullptr, 0, 1}, {"wino_slice_mb", nullptr, &Options::wino_slice_mb, 0, 1LL << 20},
+    {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
+    {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
+    {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"s2_poly", &Options::s2_poly, nullptr, 0, 1},
+    {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
+};
+const OptEntry* find_option(const char* name) {
+    if (name) for (const OptEntry& e : OPTIONS) if (!strcmp(e.name, name)) return &e;
+    return nullptr;
+}
+}  // namespace
+
+int ffr_set_option(ffr_handle* h, const char* name, long long value) {
+    if (!h) return fail(nullptr, FFR_ERR_ARG, "null handle");
+    const OptEntry* e = find_option(name);
+    if (!e) return fail(h, FFR_ERR_ARG, "ffr_set_option: unknown option '%s'", name ? name : "(null)");
+    if (value < e->lo || value > e->hi) return fail(h, FFR_ERR_ARG, "ffr_set_option: %s = %lld is outside [%lld, %lld]", name, value, e->lo, e->hi);
+#ifndef FFR_TRACE
+    if ((e->i == &Options::wf_trace || e->i == &Options::igemm_trace) && value)
+        return fail(h, FFR_ERR_UNSUPPORTED, "ffr_set_option: %s needs a -DFFR_TRACE build of the library (tools/trace_build.py)", name);
+#endif
+    if (e->i == &Options::wino_112 && h->opt.wino_112 != (int)value && h->arena) {
+        // the workspace layout depends on it: drop the arena, the next call lays it out again
+        FFR_DEVICE_SCOPE(h);
+        hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; ++h->generation;
+    }
+    if (e->i) h->opt.*(e->i) = (int)value; else h->opt.*(e->l) = value;
+    return FFR_OK;
+}
+
+int ffr_get_option(const ffr_handle* h, const char* name, long long* value) {
+    if (!h || !value) return fail(nullptr, FFR_ERR_ARG, "ffr_get_option: bad arguments");
+    const OptEntry* e = find_option(name);
+    if (!e) return fail(const_cast<ffr_handle*>(h), FFR_ERR_ARG, "ffr_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = e->i ? (long long)(h->opt.*(e->i)) : h->opt.*(e->l);
+    return FFR_OK;
+}
+
 int ffr_probe_mfma_peak(ffr_handle* h, int iters, double* tflops, double* clock_ghz, void* stream) {
     FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, 1));
     if (iters <= 0 || !tflops) return fail(h, FFR_ERR_ARG, "ffr_probe_mfma_peak: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = 256 * 2;                    // 2 blocks of 4 waves per CU
-    unsigned long long* stamps = nullptr;
-    float* sink = nullptr;
-    HIPCK(h, hipMalloc((void**)&stamps, (size_t)blocks * 4 * sizeof(unsigned long long)));
-    HIPCK(h, hipMalloc((void**)&sink, (size_t)blocks * 256 * sizeof(float)));
-    hipEvent_t e0, e1;
-    HIPCK(h, hipEventCreate(&e0)); HIPCK(h, hipEventCreate(&e1));
-    for (int rep = 0; rep < 3; ++rep) HIPCK(h, launch_mfma_probe(iters, blocks, stamps, sink, st));   // warm the clock
-    HIPCK(h, hipEventRecord(e0, st));
-    HIPCK(h, launch_mfma_probe(iters, blocks, stamps, sink, st));
-    HIPCK(h, hipEventRecord(e1, st));
-    HIPCK(h, hipEventSynchronize(e1));
+    const int blocks = h->num_cus * 2;             // 2 blocks of 4 waves per CU
+    struct Res {                                   // released on every path
+        unsigned long long* stamps = nullptr; float* sink = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Res() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); if (stamps) hipFree(stamps); if (sink) hipFree(sink); }
+    } r;
+    HIPCK(h, hipMalloc((void**)&r.stamps, (size_t)blocks * 4 * sizeof(unsigned long long)));
+    HIPCK(h, hipMalloc((void**)&r.sink, (size_t)blocks * 256 * sizeof(float)));
+    HIPCK(h, hipEventCreate(&r.e0)); HIPCK(h, hipEventCreate(&r.e1));
+    for (int rep = 0; rep < 3; ++rep) HIPCK(h, launch_mfma_probe(iters, blocks, r.stamps, r.sink, st));   // warm the clock
+    HIPCK(h, hipEventRecord(r.e0, st));
+    HIPCK(h, launch_mfma_probe(iters, blocks, r.stamps, r.sink, st));
+    HIPCK(h, hipEventRecord(r.e1, st));
+    HIPCK(h, hipEventSynchronize(r.e1));
     float ms = 0.f;
-    HIPCK(h, hipEventElapsedTime(&ms, e0, e1));
+    HIPCK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
     std::vector<unsigned long long> sv((size_t)blocks * 4);
-    HIPCK(h, hipMemcpy(sv.data(), stamps, sv.size() * 8, hipMemcpyDeviceToHost));
+    HIPCK(h, hipMemcpy(sv.data(), r.stamps, sv.size() * 8, hipMemcpyDeviceToHost));
+    // shader clock = s_memtime ticks per s_memrealtime tick; the latter is the constant 100 MHz reference counter of
+    // gfx9 (cross-checked against the hipEvent time of the same launch below: the two agree within 1 % on the MI355X)
     double ghz = 0;
     for (int b = 0; b < blocks; ++b) ghz += (double)(sv[b * 4 + 1] - sv[b * 4 + 0]) / ((double)(sv[b * 4 + 3] - sv[b * 4 + 2]) * 10.0);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(stamps); hipFree(sink);
     // 4 waves x 16 MFMAs of 32x32x2 (4096 FLOP each) per iteration and block
     *tflops = (double)blocks * 4.0 * iters * 16.0 * 4096.0 / ((double)ms * 1e-3) / 1e12;
     if (clock_ghz) *clock_ghz = ghz / blocks;
@@ -1142,10 +1209,15 @@ int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
         float ms = 0.f;
         HIPCK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
         out[r.kc].launches += 1;
-        if (!r.side) out[r.kc].ms += ms;     // second-stream work overlaps a main-stream launch that is already counted
-        out[r.kc].flops += r.flops;
-        out[r.kc].bytes += r.bytes;
-        out[r.kc].flops_executed += r.fexec;
+        // second-stream work (the few images split off a fused Winograd launch) overlaps a main-stream launch whose time is
+        // already counted: neither its time nor its work enters the per-class figures, so every TFLOP/s and TB/s derived
+        // from them divides work by the time that work took
+        if (!r.side) {
+            out[r.kc].ms += ms;
+            out[r.kc].flops += r.flops;
+            out[r.kc].bytes += r.bytes;
+            out[r.kc].flops_executed += r.fexec;
+        }
         h->ev_pool.push_back(r.e0);
         h->ev_pool.push_back(r.e1);
     }
@@ -1193,7 +1265,7 @@ int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, 
         c.out = out; c.out_pitch = cout; c.out_coff = 0; c.cout_store = cout;
         c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
         c.winoV = w.winoV; c.winoM = w.winoM; c.wino_cap = w.wino_cap;
-        c.wino_mode = use_wino;        // 0 direct, 1 Winograd fused (k_wino_fused), 2 Winograd as batched GEMM + transform kernels
+        c.wino_mode = use_wino;        // 0 direct, 1 Winograd fused (k_wino_fused, 32 x 64 blocks), 2 Winograd as batched GEMM + transform kernels, 3 fused with 32 x 32 blocks
         rc = run_conv(h, L, c, st);
         if (rc == FFR_OK && use_wino && (size_t)36 * N * ((H + 3) / 4) * ((W + 3) / 4) * (L.cin_pad > L.cout_pad ? L.cin_pad : L.cout_pad) > w.wino_cap)
             rc = fail(h, FFR_ERR_NOMEM, "Winograd scratch too small for this test shape");

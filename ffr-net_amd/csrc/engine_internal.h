@@ -40,6 +40,29 @@ struct Block {
     float* fc2 = nullptr;
 };
 
+// Experiment knobs (ffr_set_option).  Defaults are the measured best; nothing is read from the
+// environment.
+struct Options {
+    int wino = 1;                 // 0: every 3x3 convolution of the inference path runs as a direct implicit GEMM
+    int wino_mincin = 64;         // smallest padded input-channel count packed for Winograd (takes effect at load time)
+    int wino_112 = 1;             // 0: no Winograd workspace for the 112x112 layer (it then runs direct)
+    int wino_fused = 1;           // 0: Winograd convolutions run as transform kernels around the batched GEMM
+    int wf_phased_maxk = 128;     // largest padded cin for which k_wino_fused transforms its own input
+    long long wf_minblocks = 200; // fewest block tiles for which the fused kernel is used
+    int wf_halfblocks = 1;        // 1: launches below wf_minblocks use the 16-tile block shape when that fills the chip
+    int se_maxtiles = 256;        // most 4x4 tiles per image for which the SE squeeze comes from the fused kernel's tile sums
+    int wf_tailsplit = 1;         // 1: images that do not fill whole rounds of block tiles run on the second stream
+    int wf_mapv = 1;              // block -> tile map of k_wino_fused (1: channel groups of a tile group share an XCD)
+    long long wino_slice_mb = 0;  // > 0: round-1 Winograd path in sub-batches of this many MiB
+    int gemm_stream = 1;          // 0: the 36 Winograd GEMMs go through k_igemm (batched) instead of k_gemm_stream
+    int gs_tile = 0;              // 1 / 2: force the 128x128 / 128x64 tile of k_gemm_stream
+    int sk_minunits = 18;         // smallest number of K-tiles a stream-K block may own
+    int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
+    int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
+    int s2_poly = 1;              // 1: stride-2 3x3 convolutions as polyphase Winograd when packed for it
+    int wf_trace = 0, igemm_trace = 0;   // -DFFR_TRACE builds only: per-launch phase stamps on stderr (synchronises)
+};
+
 struct ProfRec {
     hipEvent_t e0, e1;
     int kc;
@@ -70,6 +93,7 @@ struct ffr_handle {
     size_t arena_bytes = 0;
     int* tickets = nullptr;      // stream-K arrival counters (zero between launches)
     size_t tickets_cap = 0;
+    ffr_eng::Options opt;
     // profiling
     bool prof = false;
     std::vector<ffr_eng::ProfRec> prof_log;
@@ -202,7 +226,7 @@ struct Work {
     size_t total;
 };
 
-Work layout(char* base, int N, int H, int W);
+Work layout(const Options& opt, char* base, int N, int H, int W);
 int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w);
 struct U8In { const unsigned char* img; const unsigned char* flip; };
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,

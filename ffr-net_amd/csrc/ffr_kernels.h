@@ -5,6 +5,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostics (per-block clock stamps) exist only in a -DFFR_TRACE build (tools/trace_build.py); the shipped library
+// compiles them out.
+#ifdef FFR_TRACE
+#define FFR_TRACE_ON(p) ((p) != nullptr)
+#else
+#define FFR_TRACE_ON(p) false
+#endif
+
 namespace ffr {
 
 // ---- implicit-GEMM convolution (igemm.hip) -----------------------------------------
@@ -19,7 +27,7 @@ struct IgemmArgs {
     const float* zero;    // >= 128 B of zeros (source of zero-padded taps)
     float* partial;       // stream-K slabs [nblocks][2][BM*BN]
     int* tickets;         // stream-K arrival counters, one per tile, zero between launches
-    unsigned long long* trace;   // diagnostic (FFR_IGEMM_TRACE): 8 words per block, or null
+    unsigned long long* trace;   // diagnostic (-DFFR_TRACE build, option "igemm_trace"): 8 words per block, or null
     int N, H, W, Ho, Wo, in_pitch, cin_pad, R, S, stride, pad, pad_mode;
     int M, KK, nkt, granule;
     int nbatch;                              // >= 1: independent GEMMs in one launch (tile id = batch-major)
@@ -80,10 +88,11 @@ struct WinoFusedArgs {
     const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
     int N, H, W, nkc;                       // nkc = cin_pad / 8
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
+    int half_n;                             // 1: blocks of 32 tiles x 32 channels (k_wino_fused<., 1>) instead of 32 x 64
     int map_v;                              // block -> tile mapping: 1 = the channel groups of a tile group share an XCD (V from its L2)
     int th, tw, mbn, nbn;                   // filled by the launcher
     long long T;
-    unsigned long long* trace;              // diagnostics (FFR_WF_TRACE): 10 words per wave, or null
+    unsigned long long* trace;              // diagnostics (-DFFR_TRACE build, option "wf_trace"): 10 words per wave, or null
 };
 int wino_fused_blocks(const WinoFusedArgs& a);
 hipError_t wino_fused_init();

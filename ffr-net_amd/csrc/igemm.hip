@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     long long u = (long long)blockIdx.x * G / gridDim.x * a.granule;
     const long long uend = (long long)(blockIdx.x + 1) * G / gridDim.x * a.granule;
     unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_seg = 0, tr_t = 0, tr_rt0 = 0;   // FFR_IGEMM_TRACE only
-    if (a.trace) tr_rt0 = __builtin_amdgcn_s_memrealtime();
+    if (FFR_TRACE_ON(a.trace)) tr_rt0 = __builtin_amdgcn_s_memrealtime();
     while (u < uend) {
     const int tile_id = (int)(u / a.nkt);
     const int kb = (int)(u - (long long)tile_id * a.nkt);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     // VGPRs alive across the MFMA loop (128x64: 196 instead of ~100 registers -> 2 blocks/CU)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    if (a.trace) { tr_t = __builtin_amdgcn_s_memtime(); ++tr_seg; }
+    if (FFR_TRACE_ON(a.trace)) { tr_t = __builtin_amdgcn_s_memtime(); ++tr_seg; }
     const int lane = tid & 63;
 
     // ---- per-thread staging rows -------------------------------------------------
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
         }
     };
 
-    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[0] += t - tr_t; tr_t = t; }
+    if (FFR_TRACE_ON(a.trace)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[0] += t - tr_t; tr_t = t; }
     // prologue: tile 0 -> stage 0, its first fragments -> slot 0
 #pragma unroll
     for (int d = 0; d < ND; ++d) dma_piece(0, d);
@@ -245,13 +245,13 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) read_piece(0, smem, pc[0], r);
     FFR_PIN;
-    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[1] += t - tr_t; tr_t = t; }
+    if (FFR_TRACE_ON(a.trace)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[1] += t - tr_t; tr_t = t; }
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll 1
     for (int it = 0; it + 1 < nk; ++it) tile_body.template operator()<false>(it & 1);
     tile_body.template operator()<true>((nk - 1) & 1);
     __builtin_amdgcn_s_setprio(2);
-    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[2] += t - tr_t; tr_t = t; }
+    if (FFR_TRACE_ON(a.trace)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[2] += t - tr_t; tr_t = t; }
 #undef FFR_PIN
 
     // ---- epilogue: accumulators -> LDS (C tile, row stride BN+4) -> whole rows, 16 B per lane ----
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     constexpr int RPP = 256 / NQ4;         // rows per pass of the 256 threads
     float* sC = smem;
     __syncthreads();                       // every wave is done reading the stage buffers
-    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[4] += t - tr_t; }
+    if (FFR_TRACE_ON(a.trace)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[4] += t - tr_t; }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
             for (int j = 0; j < TN; ++j) sC[ml * LDC + wn * WN + j * 32 + frow] = acc[i][j][r];
         }
     __syncthreads();
-    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[5] += t - tr_t; }
+    if (FFR_TRACE_ON(a.trace)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[5] += t - tr_t; }
     const int erow = tid / NQ4, ecol = (tid - erow * NQ4) * 4;
     bool finish = true;                    // this block applies the epilogue and stores the tile
     if (nk != a.nkt) {
@@ -414,9 +414,9 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
             }
         }
     }
-    if (a.trace) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[3] += t - tr_t; tr_t = t; }
+    if (FFR_TRACE_ON(a.trace)) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[3] += t - tr_t; tr_t = t; }
     }   // stream-K segment loop
-    if (a.trace && threadIdx.x == 0) {
+    if (FFR_TRACE_ON(a.trace) && threadIdx.x == 0) {
         unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
         t[0] = tr_acc[0]; t[1] = tr_acc[1]; t[2] = tr_acc[2]; t[3] = tr_acc[3]; t[4] = tr_seg;
         t[5] = tr_rt0; t[6] = __builtin_amdgcn_s_memrealtime(); t[7] = (tr_acc[4] << 32) | (tr_acc[5] & 0xffffffffull);

@@ -40,7 +40,7 @@ struct TScratch {
     float* edgeA = nullptr; size_t edgeA_floats = 0;     // gathered operands of the bottom-row / right-column GEMMs
     float* edgeW = nullptr; size_t edgeW_floats = 0;     // their weights
     float* edgeO = nullptr; size_t edgeO_floats = 0;     // their outputs [imgs*9 + imgs*8][need_pad]
-    bool wino = !(getenv("FFR_TRAIN_WINO") && atoi(getenv("FFR_TRAIN_WINO")) == 0);   // ffr_train_option("winograd")
+    bool wino = true;   // ffr_train_option("winograd")
     bool fold = true;                              // ffr_train_option("fold_channel")
 };
 
@@ -409,7 +409,8 @@ int get_train(ffr_handle* h, TrainState** t) {
     if (!h) return fail(nullptr, FFR_ERR_ARG, "null handle");
     if (!h->train) return fail(h, FFR_ERR_STATE, "ffr_train_init has not been called");
     int cur = -1;
-    if (hipGetDevice(&cur) != hipSuccess || cur != h->device) return fail(h, FFR_ERR_HIP, "hipSetDevice(%d) failed", h->device);
+    if (hipGetDevice(&cur) != hipSuccess) return fail(h, FFR_ERR_HIP, "hipGetDevice failed");
+    if (cur != h->device) return fail(h, FFR_ERR_HIP, "current device %d != handle device %d (entry point without FFR_DEVICE_SCOPE?)", cur, h->device);
     *t = h->train;
     return FFR_OK;
 }

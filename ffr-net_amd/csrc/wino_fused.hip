@@ -172,7 +172,10 @@ constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias 
 //                 with the MFMAs (one wave per SIMD, all registers taken) and costs ~13k cycles per block and 32 channels,
 //                 so it pays where the separate transform kernel costs more than that per block: K = 64, whose V
 //                 (0.46 .. 1.85 GB per layer) makes the round trip through HBM.
-template <bool PHASED>
+// NT = 32-channel halves per block: 2 = the 32-tile x 64-channel block tile; 1 = 32 tiles x 32 channels (half the
+// accumulators and half the work per block: twice as many blocks for launches that would leave CUs idle or run a
+// nearly empty last round -- small batches, stage 4 and RecNet at 128 images per GPU).
+template <bool PHASED, int NT>
 __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -198,13 +201,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     if (mb >= a.mbn) return;
     const int nkc = a.nkc;
     unsigned long long st0 = 0, st1 = 0, st2 = 0, se[4] = {0, 0, 0, 0};      // FFR_WF_TRACE (diagnostics): shader-clock stamps of the phases
-    if (a.trace) st0 = __builtin_amdgcn_s_memtime();
+    if (FFR_TRACE_ON(a.trace)) st0 = __builtin_amdgcn_s_memtime();
     // epilogue tables (their LDS is never aliased; the epilogue's first barrier publishes them)
     const int tid = threadIdx.x;
-    const int n0 = nb * 64;
+    const int n0 = nb * (32 * NT);
     float* const s_bias = smem + WF_EPI_FLOATS;                       // [9][64] border-class biases of this channel group
     int* const s_tile = reinterpret_cast<int*>(s_bias + 9 * 64);     // [32][8]: origin pixel, valid rows | cols << 8, border rows, border cols, image base pixel, 4ty-1, 4tx-1
-    for (int i = tid; i < (a.border_bias ? 9 : 1) * 64; i += 256) s_bias[i] = a.bias[(size_t)(i >> 6) * a.cout_pad + n0 + (i & 63)];
+    for (int i = tid; i < (a.border_bias ? 9 : 1) * 64; i += 256)
+        if ((i & 63) < 32 * NT) s_bias[i] = a.bias[(size_t)(i >> 6) * a.cout_pad + n0 + (i & 63)];
     if (tid < 32) {
         const long long t = (long long)mb * 32 + tid;
         int pix0 = 0, vrc = 0, br = 0, bc = 0, ibase = 0, h0 = 0, w0 = 0;
@@ -227,16 +231,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 
     // operand streams of this wave: one 16-byte fragment per lane, xi and K chunk (lane-linear in memory)
     const float* vp = PHASED ? nullptr : a.Vc + ((size_t)mb * nkc * 36 + 9 * wave) * 256 + lane * 4;
-    const float* up = a.Uc + ((size_t)nb * nkc * 36 + 9 * wave) * 512 + lane * 4;
+    // U is packed per 64-channel group: [cout_pad/64][K chunk][xi][2 halves][64 lanes][4]
+    const float* up = NT == 2 ? a.Uc + ((size_t)nb * nkc * 36 + 9 * wave) * 512 + lane * 4
+                              : a.Uc + ((size_t)(nb >> 1) * nkc * 36 + 9 * wave) * 512 + (nb & 1) * 256 + lane * 4;
     const int rowl = lane & 31;
 
     // 18 accumulator tiles = 288 registers, but a wave addresses 256 AGPRs + 256 VGPRs and hipcc keeps every builtin
     // MFMA accumulator in AGPRs (a 17th tile is copied in and out around each of its MFMAs, with the full MFMA
     // latency exposed): xi 0..7 of the wave use the builtin (16 tiles, all 256 AGPRs), xi 8 the VGPR form of the same
     // instruction through inline asm (accv, 32 VGPRs)
-    f32x16 acc[8][2], accv[2];
+    f32x16 acc[8][NT], accv[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             accv[nt][r] = 0.f;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #define FFR_PIN __builtin_amdgcn_sched_barrier(0)
     if constexpr (!PHASED) {
     // fragment registers: slot j holds (V, U lo, U hi) of xi j for the K chunk that consumes it next
-    f32x4 fv[9], fu[9][2];
+    f32x4 fv[9], fu[9][NT];
     auto load = [&](int j, int part, const float* v, const float* u) {
         if (part == 0) fv[j] = *reinterpret_cast<const f32x4*>(v + j * 256);
         else fu[j][part - 1] = *reinterpret_cast<const f32x4*>(u + j * 512 + (part - 1) * 256);
@@ -255,20 +261,21 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // ---- prologue: xi 0..7 of K chunk 0 in flight (xi 8 follows in step 0) ----
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        load(j, 0, vp, up); load(j, 1, vp, up); load(j, 2, vp, up);
+#pragma unroll
+        for (int part = 0; part <= NT; ++part) load(j, part, vp, up);
     }
     FFR_PIN;
-    if (a.trace) st1 = __builtin_amdgcn_s_memtime();
+    if (FFR_TRACE_ON(a.trace)) st1 = __builtin_amdgcn_s_memtime();
 
     // one K chunk: 9 steps (xi) of 8 MFMAs; every step reloads the slot the previous step consumed, 8 steps ahead of
     // its next use.  vp/up point at the chunk being multiplied.  LAST: no chunk follows.
     auto chunk = [&]<bool LAST>() {
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const f32x4 av = fv[j], b0 = fu[j][0], b1 = fu[j][1];
+            const f32x4 av = fv[j], b0 = fu[j][0], b1 = fu[j][NT - 1];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int e = g >> 1, nt = g & 1;
+            for (int g = 0; g < 4 * NT; ++g) {
+                const int e = g / NT, nt = g % NT;
                 if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
                 else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
                 // the step's three loads go out back to back in ONE MFMA gap: an MFMA whose gap carries vector-memory
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 // each of three gaps, 5.15k with three loads in one gap, 4.70k without loads)
                 if (g == 1) {
 #pragma unroll
-                    for (int part = 0; part < 3; ++part) {
+                    for (int part = 0; part <= NT; ++part) {
                         if (j == 0) load(8, part, vp, up);                                     // xi 8 of this chunk
                         else if (!LAST) load(j - 1, part, vp + 36 * 256, up + 36 * 512);       // xi j-1 of the next chunk
                     }
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // per thread keep the 36 patch values at 72 registers (four channels = 144 registers spilled the accumulators of
     // xi 8 into the MFMA chunks: 7.9k instead of 5.1k cycles per K chunk).
     const int tp = lane & 15;
-    f32x4 fu[9][2];
+    f32x4 fu[9][NT];
     auto loadu = [&](int j, int part, const float* u) {
         fu[j][part] = *reinterpret_cast<const f32x4*>(u + j * 512 + part * 256);
     };
@@ -321,11 +328,11 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     constexpr unsigned OOB = 0x40000000u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const int nph = nkc >> 2;
-    if (a.trace) st1 = __builtin_amdgcn_s_memtime();
+    if (FFR_TRACE_ON(a.trace)) st1 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int ph = 0; ph < nph; ++ph) {
         unsigned long long tp0 = 0;
-        if (a.trace) tp0 = __builtin_amdgcn_s_memtime();
+        if (FFR_TRACE_ON(a.trace)) tp0 = __builtin_amdgcn_s_memtime();
         const unsigned soff = (unsigned)(ph * 32) * 4u;                   // scalar: the phase's first channel
             // byte offsets of the 6 patch rows / columns of this thread's two tiles (recomputed per phase: 24 registers held
             // across the MFMA chunks spilled accumulators into them, measured 18.04 vs 17.85 ms per forward)
@@ -384,13 +391,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 // the registers of the finished rows take this phase's first weight fragments
                 if (sh == 1 && i >= 2) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) { loadu((i - 2) * 2 + q, 0, up); loadu((i - 2) * 2 + q, 1, up); }
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int part = 0; part < NT; ++part) loadu((i - 2) * 2 + q, part, up);
                 }
             }
         }
-        if (a.trace) se[0] += __builtin_amdgcn_s_memtime() - tp0;       // diagnostics: transform (before the barrier)
+        if (FFR_TRACE_ON(a.trace)) se[0] += __builtin_amdgcn_s_memtime() - tp0;       // diagnostics: transform (before the barrier)
         __syncthreads();
-        if (a.trace) se[1] += __builtin_amdgcn_s_memtime() - tp0;       // ... incl. the barrier
+        if (FFR_TRACE_ON(a.trace)) se[1] += __builtin_amdgcn_s_memtime() - tp0;       // ... incl. the barrier
         reada(0, 0, 0);
         // -- 4 K chunks: 9 steps of 8 MFMAs; A fragment of the next step from LDS, weight fragments 8 steps ahead --
 #pragma unroll
@@ -398,21 +407,21 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const int cur = (c * 9 + j) & 1;
-                const f32x4 av = af[cur], b0 = fu[j][0], b1 = fu[j][1];
+                const f32x4 av = af[cur], b0 = fu[j][0], b1 = fu[j][NT - 1];
                 const bool has_next = !(c == 3 && j == 8);
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int e = g >> 1, nt = g & 1;
+                for (int g = 0; g < 4 * NT; ++g) {
+                    const int e = g / NT, nt = g % NT;
                     if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
                     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
                     if (g == 1) {              // both weight loads of the step in one MFMA gap (see the unphased loop)
 #pragma unroll
-                        for (int part = 0; part < 2; ++part) {
+                        for (int part = 0; part < NT; ++part) {
                             if (j == 0) loadu(8, part, up);                                // xi 8 of this chunk
                             else if (c < 3) loadu(j - 1, part, up + 36 * 512);             // xi j-1 of the next chunk
                         }
                     }
-                    if (g == 4 && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
+                    if (g == 2 * NT && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
                     FFR_PIN;
                 }
             }
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     }
     }
 #undef FFR_PIN
-    if (a.trace) st2 = __builtin_amdgcn_s_memtime();
+    if (FFR_TRACE_ON(a.trace)) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue ----------------------------------------------------------------------------------------
     // One wave per SIMD: this phase is bound by instruction issue (~4.5 cycles each, packed fp32 twice that), so it is
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     const int cq = lane & 7;                        // channel quad of this lane within the 32-channel half
     const bool vec4 = ((a.out_pitch | a.out_coff | a.res_pitch) & 3) == 0;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         // E[xi][tile][co]: the 32-channel half nt of all 32 tiles
 #pragma unroll
         for (int j = 0; j < 9; ++j)
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
             for (int r = 0; r < 16; ++r)
                 smem[((9 * wave + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + rowl] = j < 8 ? acc[j][nt][r] : accv[nt][r];
         __syncthreads();
-        if (a.trace && !PHASED) se[2 * nt] = __builtin_amdgcn_s_memtime();
+        if (FFR_TRACE_ON(a.trace) && !PHASED) se[2 * nt] = __builtin_amdgcn_s_memtime();
         // one (tile, 4 channels) per thread: a wave-instruction reads / stores 8 tiles x 128 bytes
         const int tl = (lane >> 3) + 8 * wave;
         const int vrc = s_tile[tl * 8 + 1];
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) at6q(tmp[i], y[i]);
             }
-            const int cl = nt * 32 + 4 * cq;            // channel within the 64-channel group
+            const int cl = nt * 32 + 4 * cq;            // channel within the block's channel group
             const int cg = n0 + cl;
             f32x4 slope = {1.f, 1.f, 1.f, 1.f};
             if (a.slope) slope = *reinterpret_cast<const f32x4*>(a.slope + cg);
@@ -553,10 +562,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)t * a.cout_pad + cg) = psum;
             }
         }
-        if (a.trace && !PHASED) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
+        if (FFR_TRACE_ON(a.trace) && !PHASED) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    if (a.trace && lane == 0) {
+    if (FFR_TRACE_ON(a.trace) && lane == 0) {
         unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 10;
         tr[0] = st0; tr[1] = st1; tr[2] = st2; tr[3] = __builtin_amdgcn_s_memtime();
         tr[6] = se[0]; tr[7] = se[1]; tr[8] = se[2]; tr[9] = se[3];
@@ -571,9 +580,13 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 }
 
 hipError_t wino_fused_init() {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wino_fused<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)k_wino_fused<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
+    const void* fns[4] = {(const void*)k_wino_fused<false, 2>, (const void*)k_wino_fused<true, 2>,
+                          (const void*)k_wino_fused<false, 1>, (const void*)k_wino_fused<true, 1>};
+    for (const void* f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 static int wf_grid(int mbn, int nbn, int map_v) {      // inverse of the block decoding in k_wino_fused
@@ -585,7 +598,7 @@ static int wf_grid(int mbn, int nbn, int map_v) {      // inverse of the block d
 
 int wino_fused_blocks(const WinoFusedArgs& a) {
     const long long T = (long long)a.N * ((a.H + 3) / 4) * ((a.W + 3) / 4);
-    return wf_grid((int)((T + 31) / 32), a.cout_pad / 64, a.map_v);
+    return wf_grid((int)((T + 31) / 32), a.cout_pad / (a.half_n ? 32 : 64), a.map_v);
 }
 
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
@@ -593,12 +606,15 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
     a.th = (a.H + 3) / 4; a.tw = (a.W + 3) / 4;
     a.T = (long long)a.N * a.th * a.tw;
     a.mbn = (int)((a.T + 31) / 32);
-    a.nbn = a.cout_pad / 64;
+    a.nbn = a.cout_pad / (a.half_n ? 32 : 64);
+    const dim3 grid(wf_grid(a.mbn, a.nbn, a.map_v));
     if (a.Vc) {
-        hipLaunchKernelGGL(k_wino_fused<false>, dim3(wf_grid(a.mbn, a.nbn, a.map_v)), dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<false, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((k_wino_fused<false, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     } else {
         if (!a.x || a.nkc % 4 || a.x_bytes == 0 || a.x_bytes > 0x40000000u) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_wino_fused<true>, dim3(wf_grid(a.mbn, a.nbn, a.map_v)), dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<true, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((k_wino_fused<true, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }

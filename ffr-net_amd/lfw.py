@@ -72,7 +72,9 @@ def get_accuracy_from_predicts(predicts, n_folds=10):
 
 # ---------------------------------------------------------------------------------
 def cosine_scores_torch(a, b):
-    """lfw_eval.py:246,248 on whatever device a, b live (used on gathered embeddings)."""
+    """lfw_eval.py:246,248 in stock torch ops: the EXPLICIT fallback for callers that bring their own
+    embed function (e.g. CPU tensors in the gloo tests).  With an Engine the scores come from the library
+    (ffr_cosine_scores)."""
     return torch.sum(a * b, dim=1) / (a.norm(dim=1) * b.norm(dim=1) + 1e-8)
 
 
@@ -99,22 +101,92 @@ def all_gather_rows(t, n_total, group=None):
     return out[:n_total]
 
 
-def calculate_distance(data_loader, embed_fn, group=None, score_fn=None):
-    """Counterpart of lfw_eval.calculate_distance(data_loader, encoder, recnet).
+def engine_of(embed_fn):
+    """The native Engine behind an embed function (Engine.embed, GraphedEmbed, pair_embed), or None."""
+    from .native import Engine, GraphedEmbed
+    if isinstance(embed_fn, Engine):
+        return embed_fn
+    if isinstance(embed_fn, GraphedEmbed):
+        return embed_fn.engine
+    owner = getattr(embed_fn, '__self__', None)
+    if isinstance(owner, Engine):
+        return owner
+    if isinstance(owner, GraphedEmbed):
+        return owner.engine
+    return getattr(embed_fn, 'engine', None)
 
-    data_loader yields dicts with img1, img2, label, idx (data/dataset.py:84-88).
-    embed_fn(img[N,3,112,112]) -> (f_new[N,512], f[N,512]) is the hot path
-    (Engine.embed, or encoder+recnet shells).  With an initialised process group each
-    rank embeds its contiguous shard of every pair batch and the embeddings are
-    all-gathered (RCCL) before scoring, so every rank returns the full arrays.
-    Returns two [n_pairs,3] float64 arrays (score, label, idx): (f_new based, f based).
+
+class pair_embed(object):
+    """embed function of an (encoder, recnet) pair as the reference calls them back to back
+    (lfw_eval.py:240-244):  img -> (f_new, f).
+
+    With the two drop-in shells (ffrnet_amd.Backbone / RecNet) both weight sets live in ONE native handle and a
+    batch runs as one ffr_embed call (the NCHW featmap between the modules is never formed); any other pair of
+    callables is simply called in the reference's order."""
+
+    def __init__(self, encoder, recnet):
+        from .modules import Backbone, RecNet
+        self.encoder, self.recnet = encoder, recnet
+        self.native = isinstance(encoder, Backbone) and isinstance(recnet, RecNet)
+        self.engine = None
+        self._rsig = None
+
+    def _bind(self, device):
+        eng = self.encoder._engine(device)              # (re)loads the encoder weights when they changed
+        rsig, keep = self.recnet._signature(device)
+        if self.engine is not eng or self._rsig != rsig:
+            eng.load_recnet(self.recnet.state_dict())
+            self.engine, self._rsig, self._keep = eng, rsig, keep
+        return eng
+
+    def bind(self, device):
+        if self.native:
+            self._bind(device)
+        return self
+
+    def __call__(self, img):
+        if not self.native:
+            featmap, f = self.encoder(img)
+            f_new, _ = self.recnet(featmap)
+            return f_new, f
+        if self.encoder.training or self.recnet.training:
+            raise NotImplementedError('ffrnet_amd.lfw: verification runs the eval() forward (train.py:103-104); '
+                                      'call encoder.eval() / recnet.eval() first')
+        self.encoder._require_native(img, 'lfw.calculate_distance')
+        return self._bind(img.device).embed(img)
+
+
+def _embed_of(encoder, recnet=None):
+    if recnet is None:
+        return encoder                                   # already an embed function
+    return pair_embed(encoder, recnet)
+
+
+def calculate_distance(data_loader, encoder, recnet=None, flag=0, use_flip=False, use_gpu=True, group=None,
+                       score_fn=None, device_scores=False):
+    """lfw_eval.calculate_distance(data_loader, encoder, recnet, flag, use_flip, use_gpu), lfw/lfw_eval.py:226-252.
+
+    `encoder, recnet`: the two modules (the drop-in shells run natively, fused), or ONE embed function
+    `embed_fn(img[N,3,112,112]) -> (f_new[N,512], f[N,512])` in `encoder`'s place (Engine.embed, GraphedEmbed)
+    with recnet=None.  data_loader yields dicts with img1, img2, label, idx (data/dataset.py:84-88); `use_gpu`
+    moves the images to the current ROCm device like the reference's `.cuda()` (:236-238).
+
+    With an initialised process group each rank embeds its contiguous shard of every pair batch and ONE
+    all-gather (RCCL) of the packed [f1_new | f2_new | f1 | f2] rows precedes scoring, so every rank returns the
+    full arrays.  Scores: `ffr_cosine_scores` whenever a native Engine is behind the embed function; the torch
+    formula only for foreign embed functions (or an explicit `score_fn`).
+    Returns two [n_pairs,3] float64 arrays (score, label, idx): (f_new based, f based); with device_scores=True
+    additionally the two fp32 score vectors still on the device.
     """
-    score_fn = score_fn or cosine_scores_torch
+    embed_fn = _embed_of(encoder, recnet)
     rank = dist.get_rank(group) if (dist and dist.is_initialized()) else 0
     world = dist.get_world_size(group) if (dist and dist.is_initialized()) else 1
     s_new, s_old, labels, idxs = [], [], [], []
+    native = engine_of(embed_fn) is not None or bool(getattr(embed_fn, 'native', False))
     for data in data_loader:
         img1, img2 = data['img1'], data['img2']
+        if native and use_gpu and not img1.is_cuda:      # lfw_eval.py:236-238; foreign embed functions get the tensors as they are
+            img1, img2 = img1.cuda(non_blocking=True), img2.cuda(non_blocking=True)
         n = img1.size(0)
         lo, hi = shard_bounds(n, rank, world)
         if hi > lo:
@@ -126,18 +198,51 @@ def calculate_distance(data_loader, embed_fn, group=None, score_fn=None):
             e = torch.zeros((0, 2048), dtype=torch.float32, device=img1.device)
         e = all_gather_rows(e, n, group)
         d = e.size(1) // 4
-        s_new.append(score_fn(e[:, :d], e[:, d:2 * d]))
-        s_old.append(score_fn(e[:, 2 * d:3 * d], e[:, 3 * d:]))
+        fn = score_fn
+        if fn is None:
+            eng = engine_of(embed_fn)
+            fn = eng.cosine_scores if (eng is not None and e.is_cuda) else cosine_scores_torch
+        s_new.append(fn(e[:, :d], e[:, d:2 * d]))
+        s_old.append(fn(e[:, 2 * d:3 * d], e[:, 3 * d:]))
         labels.append(torch.as_tensor(data['label']).reshape(-1).double().cpu())
         idxs.append(torch.as_tensor(data['idx']).reshape(-1).double().cpu())
-    s_new = torch.cat(s_new).double().cpu().numpy()      # one device->host sync at the end
-    s_old = torch.cat(s_old).double().cpu().numpy()
+    dev_new, dev_old = torch.cat(s_new), torch.cat(s_old)
+    h_new = dev_new.double().cpu().numpy()      # one device->host sync at the end
+    h_old = dev_old.double().cpu().numpy()
     lab, idx = torch.cat(labels).numpy(), torch.cat(idxs).numpy()
-    return np.array([s_new, lab, idx]).T, np.array([s_old, lab, idx]).T
+    out = (np.array([h_new, lab, idx]).T, np.array([h_old, lab, idx]).T)
+    if device_scores:
+        return out + (dev_new.float(), dev_old.float())
+    return out
 
 
-def get_avg_accuracy(embed_fn, data_loader, group=None, n_folds=10):
-    """-> (avg_acc_new, avg_acc), as lfw_eval.get_avg_accuracy(encoder, recnet, loader)."""
-    pred_new, pred = calculate_distance(data_loader, embed_fn, group)
-    return (get_accuracy_from_predicts(pred_new, n_folds)[0],
-            get_accuracy_from_predicts(pred, n_folds)[0])
+def get_avg_accuracy(encoder, recnet=None, data_loader=None, flag=0, verbose=False, group=None, n_folds=10,
+                     details=False):
+    """lfw_eval.get_avg_accuracy(encoder, recnet, data_loader, flag, verbose), lfw/lfw_eval.py:272-287
+    -> (avg_acc_new, avg_acc).  Also callable as get_avg_accuracy(embed_fn, data_loader).
+
+    The ten `get_fold_accuracy` calls the reference spreads over a process pool (:276-283; forking after HIP
+    initialisation is unsafe) run as ONE device launch per score vector (`ffr_lfw_fold_accuracy`: same thresholds,
+    same `>` / last-argmax rules, bit-equal numbers) whenever a native Engine is behind the embed function; the
+    numpy restatement above serves foreign embed functions."""
+    if data_loader is None:                              # (embed_fn, data_loader)
+        encoder, recnet, data_loader = encoder, None, recnet
+    embed_fn = _embed_of(encoder, recnet)
+    pred_new, pred, dev_new, dev_old = calculate_distance(data_loader, embed_fn, None, flag, group=group,
+                                                          device_scores=True)
+    eng = engine_of(embed_fn)
+    if eng is not None and dev_new.is_cuda:
+        lab = torch.from_numpy(pred_new[:, 1].astype(np.int32))
+        acc_new, res_new = eng.lfw_fold_accuracy(dev_new, lab, n_folds)
+        acc, res = eng.lfw_fold_accuracy(dev_old, lab, n_folds)
+    else:
+        acc_new, res_new = get_accuracy_from_predicts(pred_new, n_folds)
+        acc, res = get_accuracy_from_predicts(pred, n_folds)
+    if verbose:
+        for name, r, a in (('f_new', res_new, acc_new), ('f', res, acc)):
+            for thr, ta in r:
+                print('Best threshold: {:.4f}; Test accuracy: {:.4f}'.format(thr, ta))
+            print('Average accuracy ({}): {}'.format(name, a))
+    if details:
+        return acc_new, acc, dict(pred_new=pred_new, pred=pred, folds_new=res_new, folds=res)
+    return acc_new, acc

@@ -10,7 +10,9 @@ state_dict key set (402 / 121 entries), so se50.pth / FFRNet.pth style checkpoin
 The parameter tree below only HOLDS weights; all arithmetic of forward() runs in
 libffrnet_hip.so (hand-written gfx950 kernels) through ffrnet_amd.native.Engine.
 The packed / BN-folded device copy is a cache owned by the native handle and is
-rebuilt whenever a parameter or buffer changes (load_state_dict, .to(), in-place edit).
+rebuilt whenever a parameter or buffer changes: every forward compares the identity and
+version counter of each tensor in the tree with what was packed (load_state_dict, .to(),
+in-place edits, a Parameter replaced on a sub-module).
 
 Backbone is eval-only (the reference never trains it, models/trainer.py:62-63); RecNet runs
 natively in eval() (label=None -> 2-tuple) and in train() mode (label given -> the 7-tuple,
@@ -69,41 +71,39 @@ class _NativeModule(nn.Module):
     _kind = None
 
     def _tensors(self):
-        """The 402 / 121 parameter and buffer tensors, listed once.  Building a state_dict per forward cost 0.9 ms
-        (measured) -- more than a small-batch forward; reading 400 version counters costs 0.05 ms.  The list is dropped
-        whenever the module tree can have changed: _apply (.to(), .float(), ...), load_state_dict, attribute
-        assignment on this module; `invalidate_native_cache()` covers hand surgery on sub-modules."""
-        lst = self.__dict__.get('_native_tensors')
-        if lst is None:
-            lst = list(self.state_dict(keep_vars=True).values())
-            self.__dict__['_native_tensors'] = lst
-        return lst
+        """Every parameter and buffer tensor of the tree (the 402 / 121 state_dict entries), read straight from the
+        sub-modules' `_parameters` / `_buffers` dicts: 0.1 ms, where building a state_dict per forward cost 0.9 ms
+        (measured) -- more than a small-batch forward.  Because the walk is repeated on every forward, replacing a
+        Parameter or buffer on ANY sub-module (`sub.weight = nn.Parameter(...)`, `load_state_dict(assign=True)`,
+        pruning, parametrisation) changes the identities below and is seen."""
+        out = []
+        for m in self.modules():
+            for t in m._parameters.values():
+                if t is not None:
+                    out.append(t)
+            for t in m._buffers.values():
+                if t is not None:
+                    out.append(t)
+        return out
 
     def invalidate_native_cache(self):
-        self.__dict__.pop('_native_tensors', None)
+        """Force a re-pack on the next forward (never needed for edits made through the module tree)."""
+        self.__dict__.pop('_native_cache', None)
 
-    def _apply(self, fn, *a, **k):
-        self.invalidate_native_cache()
-        return super()._apply(fn, *a, **k)
-
-    def load_state_dict(self, *a, **k):
-        self.invalidate_native_cache()
-        return super().load_state_dict(*a, **k)
-
-    def __setattr__(self, name, value):
-        if isinstance(value, (torch.Tensor, nn.Module)):
-            self.invalidate_native_cache()
-        super().__setattr__(name, value)
+    def _signature(self, device):
+        """(device, identity and version of every tensor).  The cache entry keeps the tensor list itself alive, so an
+        id() cannot be reused by a new tensor while it is part of a stored signature."""
+        lst = self._tensors()
+        return (device.index, tuple(id(t) for t in lst), tuple(t._version for t in lst)), lst
 
     def _engine(self, device):
-        lst = self._tensors()
-        sig = (device.index, id(lst), tuple(t._version for t in lst))
+        sig, lst = self._signature(device)
         cache = self.__dict__.setdefault('_native_cache', {})
         ent = cache.get(device.index)
         if ent is None or ent[0] != sig:
             eng = ent[1] if ent is not None else Engine(device.index)
             getattr(eng, 'load_' + self._kind)(self.state_dict())
-            cache[device.index] = (sig, eng)
+            cache[device.index] = (sig, eng, lst)
             ent = cache[device.index]
         return ent[1]
 
@@ -125,7 +125,7 @@ class _NativeModule(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ('_native_cache', '_native_tensors'):
+            if k == '_native_cache':
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -41,8 +41,20 @@ class ConvDesc(C.Structure):
                 ('tile', C.c_int), ('splitk', C.c_int)]
 
 
+_LIB_PATH = os.path.join(_HERE, 'libffrnet_hip.so')
+
+
 def lib_path():
-    return os.path.join(_HERE, 'libffrnet_hip.so')
+    return _LIB_PATH
+
+
+def set_library(path):
+    """Use another build of the library (tools/trace_build.py: the -DFFR_TRACE diagnostics build).  Must be called
+    before the first Engine is created; the product never calls it."""
+    global _LIB_PATH
+    if _LIB is not None:
+        raise RuntimeError('ffrnet_amd: the native library is already loaded')
+    _LIB_PATH = os.path.abspath(path)
 
 
 # every symbol include/ffrnet.h declares: (name, restype, argtypes)
@@ -63,6 +75,8 @@ SYMBOLS = [
     ('ffr_workspace_bytes', C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_reserve', C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_generation', C.c_ulonglong, [_P]),
+    ('ffr_set_option', C.c_int, [_P, C.c_char_p, C.c_longlong]),
+    ('ffr_get_option', C.c_int, [_P, C.c_char_p, C.POINTER(C.c_longlong)]),
     ('ffr_probe_mfma_peak', C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
     ('ffr_profile_enable', C.c_int, [_P, C.c_int]),
     ('ffr_profile_read', C.c_int, [_P, C.POINTER(KClassStat)]),
@@ -293,6 +307,26 @@ class Engine(object):
     def reserve(self, n, h=112, w=112):
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_reserve(self._h, n, h, w))
+
+    def set_option(self, name, value):
+        """Experiment knob of this handle (include/ffrnet.h: ffr_set_option); the library reads no environment."""
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.ffr_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_longlong(0)
+        self._ck(self.lib.ffr_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def set_options_from_env(self, prefix='FFR_OPT_'):
+        """tools/ only: FFR_OPT_<NAME>=<int> in the environment of a measurement script -> set_option(name, int).
+        Read here, in the script's own host code; libffrnet_hip.so itself never looks at the environment."""
+        done = {}
+        for k, v in sorted(os.environ.items()):
+            if k.startswith(prefix):
+                self.set_option(k[len(prefix):].lower(), int(v))
+                done[k[len(prefix):].lower()] = int(v)
+        return done
 
     def generation(self):
         """Changes whenever the handle released device memory a captured hipGraph may point into."""

@@ -150,6 +150,26 @@ typedef struct {
                                execute 36/144 of the direct MACs, plus tile padding)       */
 } ffr_kclass_stat;
 int ffr_profile_enable(ffr_handle* h, int on);
+/* Experiment knobs of one handle.  The library reads NO environment variable: every kernel-selection
+ * choice that can be switched for an A/B measurement is an option here, and every setting computes the same
+ * results (tests/test_gpu_parity.py::test_experiment_knobs_keep_parity).  Defaults = the measured best.
+ *   "wino" (1)            0: every 3x3 convolution of the inference path is a direct implicit GEMM
+ *   "wino_mincin" (64)    smallest padded input-channel count packed for Winograd; set BEFORE ffr_load_*
+ *   "wino_112" (1)        0: no Winograd workspace for the 112x112 layer (it runs direct; smaller arena)
+ *   "wino_fused" (1)      0: Winograd convolutions run as transform kernels around a batched GEMM (round-1 path)
+ *   "wf_phased_maxk" (128) largest padded cin for which k_wino_fused transforms its own input
+ *   "wf_minblocks" (200)  fewest 32-tile x 64-channel block tiles for which k_wino_fused is used
+ *   "wf_halfblocks" (1)   1: below that limit the 16-tile block shape is used when it fills the chip
+ *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
+ *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
+ *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
+ *   "s2_poly" (1)         1: stride-2 3x3 convolutions run as polyphase Winograd where packed for it
+ *   "gemm_stream" (1), "gs_tile" (0), "sk_minunits" (18), "wino_oi" (1), "wino_slice_mb" (0)   round-1 path details
+ *   "wf_trace", "igemm_trace" (0)   per-launch phase stamps on stderr; only in a -DFFR_TRACE build (tools/trace_build.py),
+ *                                    the shipped library returns FFR_ERR_UNSUPPORTED
+ * Unknown names and out-of-range values return FFR_ERR_ARG.                                                        */
+int ffr_set_option(ffr_handle* h, const char* name, long long value);
+int ffr_get_option(const ffr_handle* h, const char* name, long long* value);
 /* Allocation generation: changes whenever device memory that a caller may have captured into a hipGraph (workspace
  * arena, stream-K tickets, packed weights, training buffers) has been released and re-allocated.  A graph captured
  * around ffr_embed must be re-captured when this value differs from the one read at capture time.               */

@@ -84,6 +84,30 @@ def test_c_abi_exports_every_declared_symbol():
         assert rc != 0 and not h.value          # no device -> error code, never a CPU path
 
 
+def test_weight_cache_sees_submodule_surgery():
+    """replacing a Parameter / buffer on a SUB-module must invalidate the packed native copy.  The
+    signature the shells compare on every forward is (identity, version) of each tensor in the tree."""
+    rec = ffrnet_amd.RecNet()
+    dev = torch.device('cuda', 0)
+    sig0, keep0 = rec._signature(dev)
+    assert len(keep0) == 121 and rec._signature(dev)[0] == sig0
+    rec.Conv4Space[0].conv2d.weight = torch.nn.Parameter(torch.zeros_like(rec.Conv4Space[0].conv2d.weight))
+    sig1, _ = rec._signature(dev)
+    assert sig1 != sig0
+    with torch.no_grad():
+        rec.Conv4Merge[0].norm.norm.running_mean.add_(1.0)              # in-place edit: version counter
+    sig2, _ = rec._signature(dev)
+    assert sig2 != sig1
+    sub = rec.ChannelFlipMerge[0].norm.norm
+    sub.load_state_dict({k: v.clone() for k, v in sub.state_dict().items()}, assign=True)
+    sig3, _ = rec._signature(dev)
+    assert sig3 != sig2
+    rec.load_state_dict(rec.state_dict())                                # copy_ into every tensor
+    assert rec._signature(dev)[0] != sig3
+    enc = ffrnet_amd.Backbone(50, 0.6, 'ir_se')
+    assert len(enc._tensors()) == 402
+
+
 def test_shard_bounds_cover_everything():
     for n in (1, 7, 512, 513):
         for world in (1, 2, 8):
@@ -115,6 +139,17 @@ loader = [dict(img1=i1[s:s+8], img2=i2[s:s+8], label=lab[s:s+8], idx=torch.arang
 pn, p = ffrnet_amd.lfw.calculate_distance(loader, counting)
 np.save(sys.argv[4] + '.%%d.npy' %% rank, np.concatenate([pn, p], 1))
 print('calls', rank, calls)
+# the reference-shaped entry point lfw_eval.get_avg_accuracy(encoder, recnet, data_loader) with two foreign
+# modules (called in the reference's order), default scoring / fold protocol, sharded over the ranks
+class Enc(torch.nn.Module):
+    def forward(self, x):
+        e = x.reshape(x.size(0), -1) @ P
+        return e.reshape(-1, 512, 1, 1), torch.tanh(e)
+class Rec(torch.nn.Module):
+    def forward(self, fm, label=None):
+        return fm.reshape(-1, 512), fm
+acc_new, acc, det = ffrnet_amd.lfw.get_avg_accuracy(Enc(), Rec(), loader, n_folds=3, details=True)
+print('acc', rank, repr(acc_new), repr(acc), float(np.abs(det['pred_new'] - pn).max()))
 dist.destroy_process_group()
 '''
 
@@ -144,6 +179,13 @@ def test_sharded_verification_two_ranks_gloo(tmp_path):
     pn, p = ffrnet_amd.lfw.calculate_distance(loader, embed)
     assert np.abs(np.concatenate([pn, p], 1) - r0).max() < 1e-5
     assert 'calls 0 [8, 8, 6]' in logs[0] and 'calls 1 [8, 8, 4]' in logs[1]
+    # get_avg_accuracy(encoder, recnet, loader): same numbers on both ranks and as the single-process protocol
+    a_new = ffrnet_amd.lfw.get_accuracy_from_predicts(pn, 3)[0]
+    a_old = ffrnet_amd.lfw.get_accuracy_from_predicts(p, 3)[0]
+    for r in range(2):
+        line = [ln for ln in logs[r].splitlines() if ln.startswith('acc %d' % r)][0].split()
+        assert abs(float(line[2]) - a_new) < 1e-12 and abs(float(line[3]) - a_old) < 1e-12 and float(line[4]) < 1e-5
+    assert 0.0 < a_new <= 1.0
 
 
 def test_checkpoint_containers_round_trip(tmp_path, specs):

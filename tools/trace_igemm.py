@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""FFR_IGEMM_TRACE=1 python tools/trace_igemm.py : per-segment clock breakdown of k_igemm on a few shapes."""
+"""python tools/trace_igemm.py : (diagnostics build, option igemm_trace) per-segment clock breakdown of k_igemm on a few shapes."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import trace_build
+trace_build.use()
 import ffrnet_amd
-eng = ffrnet_amd.Engine(0); eng.reserve(256)
+eng = ffrnet_amd.Engine(0); eng.set_option('igemm_trace', 1); eng.reserve(256)
 def conv(name, N, H, W, cin, cout, R, stride, tile, flags=0):
     pad = R // 2
     x = torch.randn(N, H, W, cin, device='cuda'); w = torch.randn(cout, R * R * cin, device='cuda') * 0.05
