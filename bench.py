@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument('--pairs-per-step', type=int, default=0,
                     help='> 0: strong scaling, this many verification pairs per step over all GPUs '
                          '(BASELINE configs[3]: 512 pairs -> 128 images per GPU at 8 GPUs)')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=INT',
+                    help='experiment knob of the native handle (ffr_set_option, DESIGN.md 3.3); repeatable')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
@@ -354,6 +356,8 @@ def main():
     sd_e = synth.synth_state_dict(spec_e)
     sd_r = synth.synth_state_dict(spec_r)
     eng = ffrnet_amd.Engine(local)
+    for kv in args.opt:
+        eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     eng.load_encoder(sd_e)
     eng.load_recnet(sd_r)
     strong = args.pairs_per_step > 0
@@ -425,8 +429,9 @@ def main():
         mine = torch.tensor([dt_local / args.steps * 1e3,
                              percentiles([a.elapsed_time(b) for a, b in evs])['median'],
                              percentiles([a.elapsed_time(b) for a, b in coll_ev])['median']], device=dev, dtype=torch.float64)
-        allr = torch.empty((world, 3), device=dev, dtype=torch.float64)
-        dist.all_gather_into_tensor(allr, mine)
+        flat = torch.empty(world * 3, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(flat, mine)
+        allr = flat.view(world, 3)
         dt = allr[:, 0].max().item() * args.steps / 1e3                      # MAX over ranks
         per_rank = {'wall_ms_per_step': [round(v, 3) for v in allr[:, 0].tolist()],
                     'step_ms_hipevents_median': [round(v, 3) for v in allr[:, 1].tolist()],
@@ -535,7 +540,7 @@ def main():
                                          'reference: BASELINE.md)',
                           'batch_per_gpu': B, 'global_batch': world * B, 'gflop_per_image': GFLOP_PER_IMAGE,
                           'parallelism': 'image-sharded x%d, RCCL all-gather of embeddings' % world},
-               'step_ms_hipevents': step_ms, 'per_rank': per_rank,
+               'step_ms_hipevents': step_ms, 'per_rank': per_rank, 'options': args.opt or None,
                'parity_checked': {'max_rel_err_vs_reference_golden_G1': parity, 'tolerance': PARITY_TOL},
                'roofline': roof, 'cpu_baseline': cpu, 'secondary': secondary}
         print(json.dumps(out))

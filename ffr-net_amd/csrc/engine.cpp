@@ -377,6 +377,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // batch 256); FFR_WF_MAPV=0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
             f.map_v = h->opt.wf_mapv ? 1 : 0;
             f.half_n = half_n ? 1 : 0;
+            f.dma = phased && h->opt.wf_dma ? 1 : 0;
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
             f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
@@ -406,12 +407,14 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     if (q[4] > r1) r1 = q[4];
                     if (q[4] < r0) r0 = q[4];
                 }
-                if (phased)      // the kernel reports per phase: input transform, wait at the barrier behind it
-                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel): %d live blocks of %d | per block (wave 0): "
-                                    "prologue %.0f loop %.0f = %d phases x (transform %.0f + barrier %.0f + 4 K chunks of %.0f) epilogue %.0f cyc | "
-                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, cnt, nb, pro / cnt, loop / cnt, f.nkc / 4,
-                            ep[0] / cnt, ep[1] / cnt, (loop / cnt / (f.nkc / 4) - ep[0] / cnt - ep[1] / cnt) / 4.0, epi / cnt,
+                if (phased) {    // the kernel reports per phase: input transform, wait at the barrier behind it
+                    const int cpp = f.dma ? 2 : 4, nph = f.nkc / cpp;          // K chunks per phase, phases
+                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel%s, %d-channel blocks): %d live blocks of %d | per block (wave 0): "
+                                    "prologue %.0f loop %.0f = %d phases x (transform %.0f + barrier %.0f + %d K chunks of %.0f) epilogue %.0f cyc | "
+                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, f.dma ? ", LDS-DMA staged" : "", half_n ? 32 : 64, cnt, nb,
+                            pro / cnt, loop / cnt, nph, ep[0] / cnt, ep[1] / cnt, cpp, (loop / cnt / nph - ep[0] / cnt - ep[1] / cnt) / cpp, epi / cnt,
                             (double)(r1 - r0) / 100.0);
+                }
                 else
                     fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
                                     "epilogue %.0f cyc (to LDS %.0f, transform+store %.0f, barrier+to LDS %.0f, transform+store %.0f, end %.0f) | block ends spread over %.1f us\n",
@@ -1124,7 +1127,7 @@ const OptEntry OPTIONS[] = {
     {"wino", &Options::wino, nullptr, 0, 1}, {"wino_mincin", &Options::wino_mincin, nullptr, 0, 1 << 20},
     {"wino_112", &Options::wino_112, nullptr, 0, 1}, {"wino_fused", &Options::wino_fused, nullptr, 0, 1},
     {"wf_phased_maxk", &Options::wf_phased_maxk, nullptr, 0, 1 << 20}, {"wf_minblocks", nullptr, &Options::wf_minblocks, 0, 1LL << 40},
-    {"wf_halfblocks", &Options::wf_halfblocks, nullptr, 0, 1},
+    {"wf_halfblocks", &Options::wf_halfblocks, nullptr, 0, 1}, {"wf_dma", &Options::wf_dma, nullptr, 0, 1},
     {"se_maxtiles", &Options::se_maxtiles, nullptr, 0, 1 << 20}, {"wf_tailsplit", &Options::wf_tailsplit, nullptr, 0, 1},
     {"wf_mapv", &Options::wf_mapv, nullptr, 0, 1}, {"wino_slice_mb", nullptr, &Options::wino_slice_mb, 0, 1LL << 20},
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},

@@ -141,10 +141,19 @@ def test_winograd_conv_matches_direct_and_torch(engine, case):
     rd = r.cuda() if resid else None
     got_d = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, 0, rd).permute(0, 3, 1, 2).cpu()
     assert rel(got_d, ref) < OP_TOL
-    for use_wino in (1, 3, 2):             # fused kernel, 32x64 blocks (full launches) / fused, 32x32 blocks (small launches) / transform kernels + batched GEMM
-        got_w = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, use_wino, rd).permute(0, 3, 1, 2).cpu()
-        assert rel(got_w, ref) < 1e-4, use_wino          # Winograd F(4,3) in fp32: measured ~2e-6
-        assert rel(got_w, got_d) < 1e-4, use_wino
+    # fused kernel with 32x64 blocks (full launches) / with 32x32 blocks (small launches) / transform kernels + batched
+    # GEMM; for cin <= 128 the fused kernel transforms its own input: from LDS-DMA staged patches (wf_dma 1) or from
+    # per-thread buffer loads (wf_dma 0)
+    for use_wino, dma in ((1, 1), (3, 1), (1, 0), (3, 0), (2, 1)):
+        if dma == 0 and cin > 128:
+            continue
+        engine.set_option('wf_dma', dma)
+        try:
+            got_w = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, use_wino, rd).permute(0, 3, 1, 2).cpu()
+        finally:
+            engine.set_option('wf_dma', 1)
+        assert rel(got_w, ref) < 1e-4, (use_wino, dma)          # Winograd F(4,3) in fp32: measured ~2e-6
+        assert rel(got_w, got_d) < 1e-4, (use_wino, dma)
 
 
 def test_trunk_stage_taps(engine, state_dicts, golden_dir):
@@ -639,7 +648,7 @@ def test_experiment_knobs_keep_parity(tmp_path):
     for name, knobs in (('mapv0', {'FFR_OPT_WF_MAPV': '0'}), ('notailsplit', {'FFR_OPT_WF_TAILSPLIT': '0'}),
                         ('sepool', {'FFR_OPT_SE_MAXTILES': '0'}), ('unfused', {'FFR_OPT_WINO_FUSED': '0'}),
                         ('phased256', {'FFR_OPT_WF_PHASED_MAXK': '256'}), ('direct', {'FFR_OPT_WINO': '0'}),
-                        ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nopoly', {'FFR_OPT_S2_POLY': '0'}),
+                        ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nodma', {'FFR_OPT_WF_DMA': '0'}), ('nopoly', {'FFR_OPT_S2_POLY': '0'}),
                         ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'})):
         got = run(name, **knobs)
         for k in ('f_new', 'f'):
