@@ -302,6 +302,35 @@ def train_workload(args, world, rank, local, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     assert all(torch.isfinite(l) for l in items)
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # executed FLOPs of the MFMA kernels of one iteration over their hipEvent time on the launch stream: k_wino_fused
+        # (encoder + RecNet forward + data gradients), k_igemm / k_gemm_stream (direct and batched-GEMM convolutions, linears)
+        # and k_wgrad (weight gradients as TN GEMMs)
+        eng.profile_enable(True)
+        nprof = 2
+        for _ in range(nprof):
+            tr.step(non, ocl, label)
+        torch.cuda.synchronize()
+        st = eng.profile_read()
+        eng.profile_enable(False)
+        cls = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches_per_step': v['launches'] // nprof,
+                   'executed_tflops': round(v['flops_executed'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] else None}
+               for k, v in st.items() if v['launches']}
+        dom = st['wino_fused']
+        dom_tf = dom['flops_executed'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] else 0.0
+        mf = [st[k] for k in ('wino_fused', 'conv_igemm', 'wgrad')]
+        mf_ms = sum(v['ms'] for v in mf)
+        mf_tf = sum(v['flops_executed'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
+        roof = {'bound': 'mfma', 'kernel': 'k_wino_fused (frozen encoder + RecNet forward + data gradients)',
+                'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'avg_launch_us': round(dom['ms'] * 1e3 / max(1, dom['launches']), 2),
+                'mfma_kernels': {'kernels': 'k_wino_fused + k_igemm/k_gemm_stream + k_wgrad', 'executed_tflops': round(mf_tf, 2),
+                                 'frac': round(mf_tf / PEAK_FP32_MFMA_TFLOPS, 4), 'ms_per_step': round(mf_ms / nprof, 3)},
+                'per_class': cls,
+                'note': 'instrumented launches only (the convolution / GEMM / weight-gradient kernels and the inference-path '
+                        'classes); BatchNorm, loss and optimiser kernels are HBM-bound and not itemised'}
     if rank == 0:
         print(json.dumps({
             'metric': 'training image pairs/sec (frozen IR-SE50 encoder + RecNet forward/backward + CosFace head + clip + Adam)',
@@ -311,7 +340,7 @@ def train_workload(args, world, rank, local, dist):
             'config': {'workload': 'configs[4]: training step, %d pairs per GPU, 112x112x3 fp32' % B,
                        'pairs_per_gpu': B, 'global_pairs': world * B,
                        'parallelism': 'data parallel x%d, one RCCL all-reduce of the flat fp32 gradient buffer per step' % world},
-            'roofline': None, 'cpu_baseline': None}))
+            'roofline': roof, 'cpu_baseline': None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -171,6 +171,37 @@ void block_table(int cin[24], int depth[24], int stride[24]) {
 }
 
 // ---- convolution dispatch --------------------------------------------------------------
+// Which form of k_wino_fused a Winograd convolution of T tiles takes: 0 = none (transform kernels + batched GEMM),
+// 1 = blocks of 32 tiles x 64 channels, 2 = blocks of 32 tiles x 32 channels.  wino_mode as in ConvCall.
+int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long T, double x_bytes, int wino_mode) {
+    if (!h->opt.wino_fused || wino_mode == 0 || wino_mode == 2) return 0;
+    if (wino_mode == 1) return 1;
+    if (wino_mode == 3) return 2;
+    const bool phased = cin_pad <= h->opt.wf_phased_maxk && x_bytes <= 1073741824.0;
+    // One block tile (all 36 xi) occupies a whole CU and cannot be cut: a launch with fewer block tiles than CUs leaves matrix
+    // cores idle, where the batched-GEMM path balances K-tiles over every CU (Conv4Space at batch 256: 32..128 block tiles of
+    // 32 x 64, 1.07 ms fused vs 0.55 ms unfused).
+    const long long min_blocks = h->opt.wf_minblocks;
+    const long long mbn = (T + 31) / 32;
+    const long long bt_full = mbn * (cout_pad / 64);
+    const bool tail_split = h->opt.wf_tailsplit != 0 && !h->opt.wf_trace;
+    // Second block shape, 32 tiles x 32 channels (half the accumulators and half the work per block, twice the blocks):
+    // for launches whose 32 x 64 block tiles cannot fill the chip (stage 4 / RecNet at 128 images: 128 block tiles) or
+    // fill their last round badly.  Not with the in-kernel input transform, which every block of a tile group would repeat.
+    auto fit = [&](long long bt) {          // share of the launch's rounds that carries work
+        const long long full = bt / h->num_cus * h->num_cus, rem = bt - full;
+        if (rem == 0 || (tail_split && full > 0 && rem * 4 <= h->num_cus)) return 1.0;
+        return (double)bt / (double)(full + h->num_cus);
+    };
+    bool half_n = false;
+    if (h->opt.wf_halfblocks && !phased) {
+        if (bt_full < min_blocks) half_n = 2 * bt_full >= min_blocks;
+        else half_n = 0.92 * fit(2 * bt_full) > fit(bt_full);       // a half block costs ~8 % more per unit of work
+    }
+    if (mbn * (cout_pad / (half_n ? 32 : 64)) < min_blocks) return 0;
+    return half_n ? 2 : 1;
+}
+
 // Tile shape and block count of one launch.
 //  * large problems (at least a quarter of a tile of K-tiles per persistent block at 128x128):
 //    persistent stream-K over 256 CUs x resident blocks, biggest tile that divides cout (tile
@@ -298,7 +329,6 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
         const long long T = (long long)c.N * th * tw;
         // GEMM + output transform in one kernel (wino_fused.hip): M never exists in memory
-        const bool fused_on = h->opt.wino_fused != 0;
         // K <= 128: the fused kernel transforms its own input (V never exists in memory); larger K: separate transform
         // kernel (measured at batch 256: 17.99 / 18.04 / 18.78 ms per forward for a limit of 64 / 128 / 256, 18.67 without)
         const int phased_maxk = h->opt.wf_phased_maxk;
@@ -307,28 +337,13 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         // One block tile (32 tiles x 64 channels, all 36 xi) occupies a whole CU and cannot be cut: a launch with fewer
         // block tiles than CUs leaves matrix cores idle, where the batched-GEMM path balances K-tiles over every CU
         // (Conv4Space at batch 256: 32..128 block tiles, 1.07 ms fused vs 0.55 ms unfused).  wino_mode 1 forces fused.
-        const long long min_blocks = h->opt.wf_minblocks;
-        const long long mbn = (T + 31) / 32;
-        const long long bt_full = mbn * (L.cout_pad / 64);
+        const int choice = wino_fused_choice(h, L.cin_pad, L.cout_pad, T, x_bytes, c.wino_mode);
+        const bool half_n = choice == 2;
         const bool tail_split = h->opt.wf_tailsplit != 0 && !h->opt.wf_trace;
-        // Second block shape, 32 tiles x 32 channels (half the accumulators and half the work per block, twice the blocks):
-        // for launches whose 32 x 64 block tiles cannot fill the chip (stage 4 / RecNet at 128 images: 128 block tiles) or
-        // fill their last round badly (128 -> 128 at 28x28 and 128 images: 392 = 1.53 rounds).  Not with the in-kernel input
-        // transform, which every block of a tile group would repeat.
-        auto fit = [&](long long bt) {          // share of the launch's rounds that carries work
-            const long long full = bt / h->num_cus * h->num_cus, rem = bt - full;
-            if (rem == 0 || (tail_split && c.wino_mode < 0 && full > 0 && rem * 4 <= h->num_cus)) return 1.0;
-            return (double)bt / (double)(full + h->num_cus);
-        };
-        bool half_n = c.wino_mode == 3;
-        if (c.wino_mode < 0 && h->opt.wf_halfblocks && !phased) {
-            if (bt_full < min_blocks) half_n = 2 * bt_full >= min_blocks;
-            else half_n = 0.92 * fit(2 * bt_full) > fit(bt_full);       // a half block costs ~8 % more per unit of work
-        }
+        const long long mbn = (T + 31) / 32;
         const int nbn = L.cout_pad / (half_n ? 32 : 64);
         const long long block_tiles = mbn * nbn;
-        const bool want_fused = c.wino_mode == 1 || c.wino_mode == 3 || (c.wino_mode < 0 && block_tiles >= min_blocks);
-        if (fused_on && want_fused && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
+        if (choice != 0 && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
             // The launch runs in rounds of one block tile per CU, all of the same duration: a last round with few block
             // tiles leaves most of the chip idle for a whole block time (784 block tiles of a 128 -> 128 layer at 28x28 =
             // 3.06 rounds took 4: 245 us where 3 rounds are 178).  When the last round would be less than a quarter full,
@@ -377,7 +392,6 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // batch 256); FFR_WF_MAPV=0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
             f.map_v = h->opt.wf_mapv ? 1 : 0;
             f.half_n = half_n ? 1 : 0;
-            f.dma = phased && h->opt.wf_dma ? 1 : 0;
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
             f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
@@ -408,10 +422,10 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     if (q[4] < r0) r0 = q[4];
                 }
                 if (phased) {    // the kernel reports per phase: input transform, wait at the barrier behind it
-                    const int cpp = f.dma ? 2 : 4, nph = f.nkc / cpp;          // K chunks per phase, phases
-                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel%s, %d-channel blocks): %d live blocks of %d | per block (wave 0): "
+                    const int cpp = 4, nph = f.nkc / cpp;                      // K chunks per phase, phases
+                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel, %d-channel blocks): %d live blocks of %d | per block (wave 0): "
                                     "prologue %.0f loop %.0f = %d phases x (transform %.0f + barrier %.0f + %d K chunks of %.0f) epilogue %.0f cyc | "
-                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, f.dma ? ", LDS-DMA staged" : "", half_n ? 32 : 64, cnt, nb,
+                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, half_n ? 32 : 64, cnt, nb,
                             pro / cnt, loop / cnt, nph, ep[0] / cnt, ep[1] / cnt, cpp, (loop / cnt / nph - ep[0] / cnt - ep[1] / cnt) / cpp, epi / cnt,
                             (double)(r1 - r0) / 100.0);
                 }
@@ -429,6 +443,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
             return FFR_OK;
         }
+        if (L.wu == L.wuc) return fail(h, FFR_ERR_STATE, "Winograd weights exist in the fused kernel's order only, but this launch cannot run fused");
         if ((size_t)36 * T * L.cin_pad <= c.wino_cap && (size_t)36 * T * L.cout_pad <= c.wino_cap && T < 0x7fffffffLL) {
             // sub-batches: V and M of one slice (36 * tiles * channels * 4 B each) should stay in the
             // 256 MiB Infinity Cache between the transform that writes them and the kernel that reads them
@@ -1127,7 +1142,7 @@ const OptEntry OPTIONS[] = {
     {"wino", &Options::wino, nullptr, 0, 1}, {"wino_mincin", &Options::wino_mincin, nullptr, 0, 1 << 20},
     {"wino_112", &Options::wino_112, nullptr, 0, 1}, {"wino_fused", &Options::wino_fused, nullptr, 0, 1},
     {"wf_phased_maxk", &Options::wf_phased_maxk, nullptr, 0, 1 << 20}, {"wf_minblocks", nullptr, &Options::wf_minblocks, 0, 1LL << 40},
-    {"wf_halfblocks", &Options::wf_halfblocks, nullptr, 0, 1}, {"wf_dma", &Options::wf_dma, nullptr, 0, 1},
+    {"wf_halfblocks", &Options::wf_halfblocks, nullptr, 0, 1},
     {"se_maxtiles", &Options::se_maxtiles, nullptr, 0, 1 << 20}, {"wf_tailsplit", &Options::wf_tailsplit, nullptr, 0, 1},
     {"wf_mapv", &Options::wf_mapv, nullptr, 0, 1}, {"wino_slice_mb", nullptr, &Options::wino_slice_mb, 0, 1LL << 20},
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},

@@ -49,7 +49,6 @@ struct Options {
     int wino_fused = 1;           // 0: Winograd convolutions run as transform kernels around the batched GEMM
     int wf_phased_maxk = 128;     // largest padded cin for which k_wino_fused transforms its own input
     long long wf_minblocks = 200; // fewest block tiles for which the fused kernel is used
-    int wf_dma = 1;               // 1: the in-kernel input transform reads patches staged in LDS by LDS-DMA (16-channel phases)
     int wf_halfblocks = 1;        // 1: launches below wf_minblocks use the 16-tile block shape when that fills the chip
     int se_maxtiles = 256;        // most 4x4 tiles per image for which the SE squeeze comes from the fused kernel's tile sums
     int wf_tailsplit = 1;         // 1: images that do not fill whole rounds of block tiles run on the second stream
@@ -201,6 +200,7 @@ struct ConvCall {
     bool* tile_sums_written = nullptr;             // set to true when the Winograd path wrote them
 };
 
+int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long T, double x_bytes, int wino_mode);
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st);
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st);
 

@@ -60,7 +60,7 @@ hipError_t launch_gemm_stream(GemmStreamArgs a, int tile, int nblocks, hipStream
 hipError_t launch_wino_in(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, int pad_mode,
                           hipStream_t stream);
 // U[36][out_pad][in_pad] = G g G^T of W[out_pad][9][in_pad] (device-side; the training step re-derives it per step)
-hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream);
+hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream, int chunked = 0);
 // weight gradient in the Winograd domain: dM[36][T][Cp] = A dy A^T per 4x4 output tile; grad[o][9][i] (+)= G^T dU G
 hipError_t launch_wino_dout(const float* dy, float* dM, int N, int H, int W, int Cp, hipStream_t stream);
 hipError_t launch_wino_dweights(const float* dU, float* grad, int out_pad, int in_pad, int accumulate, hipStream_t stream);
@@ -88,7 +88,6 @@ struct WinoFusedArgs {
     const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
     int N, H, W, nkc;                       // nkc = cin_pad / 8
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
-    int dma;                                // phased mode: 1 = raw patches staged in LDS by LDS-DMA in 16-channel phases (MODE 2)
     int half_n;                             // 1: blocks of 32 tiles x 32 channels (k_wino_fused<., 1>) instead of 32 x 64
     int map_v;                              // block -> tile mapping: 1 = the channel groups of a tile group share an XCD (V from its L2)
     int th, tw, mbn, nbn;                   // filled by the launcher

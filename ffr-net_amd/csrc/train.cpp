@@ -41,6 +41,7 @@ struct TScratch {
     float* edgeW = nullptr; size_t edgeW_floats = 0;     // their weights
     float* edgeO = nullptr; size_t edgeO_floats = 0;     // their outputs [imgs*9 + imgs*8][need_pad]
     bool wino = true;   // ffr_train_option("winograd")
+    int fused = 1;      // ffr_train_option("fused"): 1 = Winograd launches that fill the chip run k_wino_fused on the live weights, 2 = all of them (tests), 0 = none
     bool fold = true;                              // ffr_train_option("fold_channel")
 };
 
@@ -64,14 +65,20 @@ int layer_forward(ffr_handle* h, const Work& w, const TLayer& L, TSaved& sv, int
     cw.pad = 1; cw.pad_mode = 1; cw.border = 0; cw.w = L.w; cw.bias = h->zero; cw.slope = nullptr; cw.wu = nullptr;
     // Winograd F(4x4,3x3) as the inference path (section 3.2 of DESIGN.md); U = G g G^T from the live weights
     const bool wino = s.wino && L.cin_pad >= 128 && s.U && (size_t)36 * L.cout_pad * L.cin_pad <= s.U_floats;
+    // ... emitted in the order k_wino_fused streams when the launch can run fused (the kernel of the inference path: GEMMs +
+    // output transform in one launch, raw convolution output for the batch statistics)
+    int fused = 0;
     if (wino) {
-        HIPCK(h, launch_wino_weights(L.w, s.U, L.cout_pad, L.cin_pad, st));
+        fused = s.fused ? wino_fused_choice(h, L.cin_pad, L.cout_pad, (long long)G * N * 4, 4.0 * G * N * 49 * sv.x_pitch, s.fused == 2 ? 1 : -1) : 0;
+        HIPCK(h, launch_wino_weights(L.w, s.U, L.cout_pad, L.cin_pad, st, fused ? 1 : 0));
         cw.wu = s.U;
+        if (fused) cw.wuc = s.U;
     }
     ConvCall c{};
     c.x = sv.x; c.N = G * N; c.H = 7; c.W = 7; c.in_pitch = sv.x_pitch;
     c.out = sv.y; c.out_pitch = L.cout_pad; c.out_coff = 0; c.cout_store = L.cout_pad;
     conv_call_common(c, w, wino);
+    if (wino) c.wino_mode = fused == 2 ? 3 : (fused == 1 ? 1 : 2);
     RC(run_conv(h, cw, c, st));
     HIPCK(h, launch_bn_stats(sv.y, L.cout_pad, G, N * 49, L.gamma, L.beta, update_running ? L.rmean : nullptr,
                              update_running ? L.rvar : nullptr, BN_MOMENTUM, BN_EPS_F, sv.bn, part, st));
@@ -99,12 +106,18 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
         a.dy = w.winoM; a.x = w.winoV; a.zero = h->zero; a.rows = (int)T; a.H = 1; a.W = 1; a.x_pitch = L.cin_pad;
         a.dy_pitch = L.cout_pad; a.cin_pad = L.cin_pad; a.taps = 1; a.pad_mode = 0; a.cout_pad = L.cout_pad;
         // dU in the U scratch (free until the data gradient re-derives its weights), split-K slabs in s.slabs
-        HIPCK(h, launch_wgrad_batched(a, s.U, 36, T * L.cout_pad, T * L.cin_pad, s.slabs, s.slab_floats, st));
+        {
+            const double fx = 2.0 * 36.0 * (double)T * L.cout_pad * L.cin_pad;
+            Scope sc(h, st, FFR_KC_WGRAD, 2.0 * rows * 9.0 * L.cout * L.cin, 4.0 * 36.0 * T * (L.cout_pad + L.cin_pad), fx);
+            HIPCK(h, launch_wgrad_batched(a, s.U, 36, T * L.cout_pad, T * L.cin_pad, s.slabs, s.slab_floats, st));
+        }
         HIPCK(h, launch_wino_dweights(s.U, L.gw, L.cout_pad, L.cin_pad, accumulate, st));
     } else {
         WgradArgs a{};
         a.dy = s.dy; a.x = sv.x; a.zero = h->zero; a.rows = rows; a.H = 7; a.W = 7; a.x_pitch = sv.x_pitch;
         a.dy_pitch = L.cout_pad; a.cin_pad = L.cin_pad; a.taps = 9; a.pad_mode = 1; a.cout_pad = L.cout_pad;
+        const double fx = 2.0 * rows * 9.0 * L.cout_pad * L.cin_pad;
+        Scope sc(h, st, FFR_KC_WGRAD, 2.0 * rows * 9.0 * L.cout * L.cin, 4.0 * rows * (L.cout_pad + L.cin_pad), fx);
         HIPCK(h, launch_wgrad(a, L.gw, accumulate, s.slabs, s.slab_floats, st));
     }
     if (!dx) return FFR_OK;
@@ -126,11 +139,14 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
         // The 9x9 padded gradient in three pieces: rows/columns 0..7 as the 'same' F(4x4,3x3) convolution of dy embedded at
         // (1,1) of an 8x8 map (2x2 tiles instead of the 3x3 a 9x9 output would need), row 8 and column 8 (only the last
         // weight row / column reaches them) as two GEMMs with K = 3*cout.
-        HIPCK(h, launch_wino_weights(s.wd, s.U, need_pad, L.cout_pad, st));
+        const int fused = s.fused ? wino_fused_choice(h, L.cout_pad, need_pad, (long long)imgs * 4, 4.0 * imgs * 64 * L.cout_pad, s.fused == 2 ? 1 : -1) : 0;
+        HIPCK(h, launch_wino_weights(s.wd, s.U, need_pad, L.cout_pad, st, fused ? 1 : 0));
         HIPCK(h, launch_embed_8x8(s.dy, s.canvas, imgs, L.cout_pad, st));
         cw.wu = s.U; cw.pad = 1;
+        if (fused) cw.wuc = s.U;
         c.x = s.canvas; c.H = 8; c.W = 8;
         conv_call_common(c, w, true);
+        c.wino_mode = fused == 2 ? 3 : (fused == 1 ? 1 : 2);
         RC(run_conv(h, cw, c, st));
         float* Eb = s.edgeA;
         float* Er = s.edgeA + (size_t)imgs * 9 * 3 * L.cout_pad;
@@ -977,6 +993,7 @@ int ffr_train_option(ffr_handle* h, const char* name, int value) {
     FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     if (!name) return fail(h, FFR_ERR_ARG, "ffr_train_option: null name");
     if (std::string(name) == "winograd") { t->sc.wino = value != 0; return FFR_OK; }
+    if (std::string(name) == "fused") { t->sc.fused = value < 0 ? 0 : (value > 2 ? 2 : value); return FFR_OK; }
     if (std::string(name) == "fold_channel") { t->sc.fold = value != 0; return FFR_OK; }
     if (std::string(name) == "adam_step") {      // resume: Adam's bias correction continues from the saved step count
         if (value < 0) return fail(h, FFR_ERR_ARG, "ffr_train_option: adam_step must be >= 0");

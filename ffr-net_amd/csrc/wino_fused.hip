@@ -166,8 +166,8 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 constexpr int WF_EPI_FLOATS = 36 * 32 * 32;  // the epilogue's E[xi][tile][32 channels] (147,456 B); the K loop uses no LDS
 constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias table + tile table = 150,784 B
 
-// PHASED = false: V comes pre-transformed from k_wino_in_c (global memory, fragment order).
-// PHASED = true : the block transforms its own input, 32 channels (4 K chunks) at a time, into LDS (147 KB, the
+// MODE 0 (PHASED = false): V comes pre-transformed from k_wino_in_c (global memory, fragment order).
+// MODE 1 (PHASED = true) : the block transforms its own input, 32 channels (4 K chunks) at a time, into LDS (147 KB, the
 //                 same bytes the epilogue uses later): V never exists in global memory.  The transform is NOT overlapped
 //                 with the MFMAs (one wave per SIMD, all registers taken) and costs ~13k cycles per block and 32 channels,
 //                 so it pays where the separate transform kernel costs more than that per block: K = 64, whose V
@@ -175,17 +175,6 @@ constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias 
 // NT = 32-channel halves per block: 2 = the 32-tile x 64-channel block tile; 1 = 32 tiles x 32 channels (half the
 // accumulators and half the work per block: twice as many blocks for launches that would leave CUs idle or run a
 // nearly empty last round -- small batches, stage 4 and RecNet at 128 images per GPU).
-// MODE 2 (round 3): as MODE 1, but the raw 6x6 patches reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds) issued in the
-// MFMA gaps of the PREVIOUS 16-channel phase, so the transform reads them from LDS instead of waiting on 72 buffer loads
-// per thread through the texture-address path: RAW[32 tiles][36 px][16 ch] (75.8 KB) next to V[2 chunks][36][64][4]
-// (73.7 KB).  A DMA instruction moves 16 pixels x 64 B of ONE tile, so the tile's geometry is wave-uniform: interior
-// tiles cost no VALU work at all (per-lane offset precomputed once, tile base in an SGPR); border tiles compute their
-// padding per lane behind a uniform branch.  Out-of-range lanes return zeros into LDS (zero padding).
-constexpr int WF2_V_FLOATS = 2 * 36 * 256;      // V image of one 16-channel phase
-constexpr int WF2_RAW_TS = 592;                 // floats per tile of the raw image: 36 px x 16 ch + 16 (consecutive tiles 16 banks apart)
-constexpr int WF2_TAB_FLOATS = WF2_V_FLOATS + 32 * WF2_RAW_TS;   // 37,376 floats; the epilogue's E (36,864) fits in front of the tables too
-constexpr int WF2_LDS_BYTES = (WF2_TAB_FLOATS + 9 * 64 + 32 * 8) * 4;   // 152,832 B
-
 template <int MODE, int NT>
 __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     constexpr bool PHASED = MODE != 0;
@@ -217,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // epilogue tables (their LDS is never aliased; the epilogue's first barrier publishes them)
     const int tid = threadIdx.x;
     const int n0 = nb * (32 * NT);
-    float* const s_bias = smem + (MODE == 2 ? WF2_TAB_FLOATS : WF_EPI_FLOATS);   // [9][64] border-class biases of this channel group
+    float* const s_bias = smem + WF_EPI_FLOATS;                       // [9][64] border-class biases of this channel group
     int* const s_tile = reinterpret_cast<int*>(s_bias + 9 * 64);     // [32][8]: origin pixel, valid rows | cols << 8, border rows, border cols, image base pixel, 4ty-1, 4tx-1
     for (int i = tid; i < (a.border_bias ? 9 : 1) * 64; i += 256)
         if ((i & 63) < 32 * NT) s_bias[i] = a.bias[(size_t)(i >> 6) * a.cout_pad + n0 + (i & 63)];
@@ -239,7 +228,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         }
         s_tile[tid * 8 + 0] = pix0; s_tile[tid * 8 + 1] = vrc; s_tile[tid * 8 + 2] = br; s_tile[tid * 8 + 3] = bc;
         s_tile[tid * 8 + 4] = ibase; s_tile[tid * 8 + 5] = h0; s_tile[tid * 8 + 6] = w0;
-        s_tile[tid * 8 + 7] = ((ibase + h0 * a.W + w0) * a.in_pitch) * 4;      // byte offset of the patch origin (MODE 2, interior tiles)
     }
 
     // operand streams of this wave: one 16-byte fragment per lane, xi and K chunk (lane-linear in memory)
@@ -442,173 +430,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         }
         __syncthreads();                                    // everybody is done reading V before the next transform
     }
-    } else {
-    // ---- MODE 2: per 16 input channels: raw patches (LDS, DMA'd during the previous phase) -> input transform -> V (LDS),
-    //      then 2 K chunks with the A fragments from LDS while the DMAs of the next phase run ----
-    float* const raw = smem + WF2_V_FLOATS;
-    // transform role: tile tl, channel pair cp of the phase's 16 channels; 16 lanes = 2 tiles x 8 pairs read 2 x 64 B that lie
-    // 16 banks apart and write 16 different bank pairs of the fragment image (position rotated by 2 tq inside groups of 8)
-    const int tl = 8 * wave + (lane >> 3), cp = lane & 7, tq = cp >> 1;
-    const float* const rawp = raw + tl * WF2_RAW_TS + cp * 2;
-    float* const vout = smem + (((tq >> 1) * 36) * 64 + (tq & 1) * 32 + (tl & 24) + ((tl + 2 * tq) & 7)) * 4 + (cp & 1) * 2;
-    int aoff[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) aoff[c] = ((lane & 32) + (lane & 24) + ((lane + 4 * c + 2 * (lane >> 5)) & 7)) * 4;
-    f32x4 fu[9][NT];
-    auto loadu = [&](int j, int part, const float* u) {
-        fu[j][part] = *reinterpret_cast<const f32x4*>(u + j * 512 + part * 256);
-    };
-    f32x4 af[2];
-    auto reada = [&](int buf, int c, int j) {
-        af[buf] = *reinterpret_cast<const f32x4*>(smem + (c * 36 + 9 * wave + j) * 256 + aoff[c]);
-    };
-    __syncthreads();                                        // the tile table is visible
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-    // DMA role of a lane: pixel 16 g + (lane >> 2) of the patch (g = 0, 1, 2; the third instruction has 4 pixels), 16-byte
-    // piece lane & 3 of its 16 channels
-    const int dq = lane & 3;
-    unsigned voff[3];
-    int pij[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const int px = 16 * g + (lane >> 2), pi = px / 6, pj = px - 6 * pi;
-        pij[g] = pi | (pj << 8);
-        voff[g] = (unsigned)((pi * a.W + pj) * a.in_pitch + dq * 4) * 4u;
-    }
-    // the wave's 8 tiles (it fetches and transforms the same ones): two wave-uniform bit masks (valid, patch entirely inside
-    // the map); the byte offset of a tile's patch origin is read from the LDS table one step before its DMAs go out
-    unsigned m_in = 0, m_ok = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int* tt = s_tile + (8 * wave + k) * 8;
-        const int vrc = __builtin_amdgcn_readfirstlane(tt[1]);
-        const int h0 = __builtin_amdgcn_readfirstlane(tt[5]), w0 = __builtin_amdgcn_readfirstlane(tt[6]);
-        if (vrc != 0) m_ok |= 1u << k;
-        if (vrc != 0 && h0 >= 0 && w0 >= 0 && h0 + 5 < a.H && w0 + 5 < a.W) m_in |= 1u << k;
-    }
-    int tb[2];
-    auto tile_base = [&](int k) { tb[k & 1] = s_tile[(8 * wave + k) * 8 + 7]; };
-    auto dma = [&](int k, int g, unsigned phoff) {
-        float* const dst = raw + (8 * wave + k) * WF2_RAW_TS + g * 256;
-        unsigned vo;
-        if ((m_in >> k) & 1u) {                          // uniform: whole patch inside the map
-            vo = voff[g] + (unsigned)tb[k & 1];
-        } else {
-            const int* tt = s_tile + (8 * wave + k) * 8;
-            int hi = tt[5] + (pij[g] & 0xff), wi = tt[6] + (pij[g] >> 8);
-            bool ok = ((m_ok >> k) & 1u) != 0;
-            if (a.pad_mode == 1) {
-                hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi); if (hi < 0) hi = 0;
-                wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi); if (wi < 0) wi = 0;
-            } else {
-                ok = ok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            }
-            vo = ok ? (unsigned)((tt[4] + hi * a.W + wi) * a.in_pitch + dq * 4) * 4u : 0x80000000u;
-        }
-        if (g < 2 || lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_PTR(dst), 16, vo, phoff, 0, 0);
-    };
-    // input transform of (tile tl, channel pair cp): 36 ds_read_b64, B^T d B, 36 ds_write_b64 into the fragment image
-    auto transform = [&]() {
-        f32x2 d[6][6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) d[i][j] = *reinterpret_cast<const f32x2*>(rawp + (i * 6 + j) * 16);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            f32x2 col[6], v[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) col[i] = d[i][j];
-            bt6t(col, v);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) d[i][j] = v[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            f32x2 v[6];
-            bt6t(d[i], v);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vout + (i * 6 + j) * 256) = v[j];
-            // the registers of the finished rows take this phase's first weight fragments
-            if (i >= 2) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int part = 0; part < NT; ++part) loadu((i - 2) * 2 + q, part, up);
-            }
-        }
-    };
-    // the MFMAs of one phase: 2 K chunks x 9 steps; weight fragments 8 steps ahead as everywhere; !LASTP: one tile's three
-    // DMAs of the next phase per step in the first 8 steps, one per MFMA gap
-    auto mfma_phase = [&]<bool LASTP>(unsigned phoff) {
-        if (!LASTP) tile_base(0);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int cur = (c * 9 + j) & 1;
-                const f32x4 av = af[cur], b0 = fu[j][0], b1 = fu[j][NT - 1];
-                const bool has_next = !(c == 1 && j == 8);
-#pragma unroll
-                for (int g = 0; g < 4 * NT; ++g) {
-                    const int e = g / NT, nt = g % NT;
-                    if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
-                    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
-                    if (g == 1) {
-#pragma unroll
-                        for (int part = 0; part < NT; ++part) {
-                            if (j == 0) loadu(8, part, up);                                        // xi 8 of this chunk
-                            else if (c == 0) loadu(j - 1, part, up + 36 * 512);                    // xi j-1 of the phase's second chunk
-                        }
-                    }
-                    if (g == 2 * NT && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
-                    if (!LASTP && c == 0 && j < 7 && g == 1) tile_base(j + 1);
-                    if (!LASTP && c == 0 && j < 8) {
-                        if (NT == 2) { if (g == 3) dma(j, 0, phoff); if (g == 5) dma(j, 1, phoff); if (g == 7) dma(j, 2, phoff); }
-                        else { if (g == 0) dma(j, 0, phoff); if (g == 2) dma(j, 1, phoff); if (g == 3) dma(j, 2, phoff); }
-                    }
-                    FFR_PIN;
-                }
-            }
-            up += 36 * 512;
-        }
-    };
-    const int nph = nkc >> 1;
-    // prologue: the raw patches of phase 0
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        tile_base(k);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) dma(k, g, 0u);
-    }
-    FFR_PIN;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (FFR_TRACE_ON(a.trace)) st1 = __builtin_amdgcn_s_memtime();
-#pragma unroll 1
-    for (int ph = 0; ph + 1 < nph; ++ph) {
-        unsigned long long tp0 = 0;
-        if (FFR_TRACE_ON(a.trace)) tp0 = __builtin_amdgcn_s_memtime();
-        transform();
-        if (FFR_TRACE_ON(a.trace)) se[0] += __builtin_amdgcn_s_memtime() - tp0;
-        __syncthreads();
-        if (FFR_TRACE_ON(a.trace)) se[1] += __builtin_amdgcn_s_memtime() - tp0;
-        reada(0, 0, 0);
-        mfma_phase.template operator()<false>((unsigned)(ph + 1) * 64u);
-        // the DMAs went out in the first 8 of the 18 steps; the only younger loads are xi 8 of the second chunk (9 steps old)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                    // everybody is done reading V before the next transform
-    }
-    {
-        unsigned long long tp0 = 0;
-        if (FFR_TRACE_ON(a.trace)) tp0 = __builtin_amdgcn_s_memtime();
-        transform();
-        if (FFR_TRACE_ON(a.trace)) se[0] += __builtin_amdgcn_s_memtime() - tp0;
-        __syncthreads();
-        if (FFR_TRACE_ON(a.trace)) se[1] += __builtin_amdgcn_s_memtime() - tp0;
-        reada(0, 0, 0);
-        mfma_phase.template operator()<true>(0u);
-        __syncthreads();
-    }
     }
 #undef FFR_PIN
     if (FFR_TRACE_ON(a.trace)) st2 = __builtin_amdgcn_s_memtime();
@@ -750,8 +571,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         tr[0] = st0; tr[1] = st1; tr[2] = st2; tr[3] = __builtin_amdgcn_s_memtime();
         tr[6] = se[0]; tr[7] = se[1]; tr[8] = se[2]; tr[9] = se[3];
         if (PHASED) {       // per phase: transform, barrier wait (reported in the first two epilogue columns)
-            const int np = MODE == 2 ? nkc >> 1 : nkc >> 2;
-            tr[6] = st2 + se[0] / np; tr[7] = tr[6] + (se[1] - se[0]) / np; tr[8] = tr[7]; tr[9] = tr[7];
+            tr[6] = st2 + se[0] / (nkc >> 2); tr[7] = tr[6] + (se[1] - se[0]) / (nkc >> 2); tr[8] = tr[7]; tr[9] = tr[7];
         }
         tr[4] = __builtin_amdgcn_s_memrealtime();
         unsigned xcc;
@@ -765,11 +585,6 @@ hipError_t wino_fused_init() {
                           (const void*)k_wino_fused<0, 1>, (const void*)k_wino_fused<1, 1>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
-        if (e != hipSuccess) return e;
-    }
-    const void* fns2[2] = {(const void*)k_wino_fused<2, 2>, (const void*)k_wino_fused<2, 1>};
-    for (const void* f : fns2) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WF2_LDS_BYTES);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -799,10 +614,7 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
         else hipLaunchKernelGGL((k_wino_fused<0, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     } else {
         if (!a.x || a.nkc % 4 || a.x_bytes == 0 || a.x_bytes > 0x40000000u) return hipErrorInvalidValue;
-        if (a.dma) {
-            if (a.half_n) hipLaunchKernelGGL((k_wino_fused<2, 1>), grid, dim3(256), WF2_LDS_BYTES, stream, a);
-            else hipLaunchKernelGGL((k_wino_fused<2, 2>), grid, dim3(256), WF2_LDS_BYTES, stream, a);
-        } else if (a.half_n) hipLaunchKernelGGL((k_wino_fused<1, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<1, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
         else hipLaunchKernelGGL((k_wino_fused<1, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     }
     return hipGetLastError();

@@ -159,8 +159,10 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
 
 // U[xi][o][i] = (G g G^T)[xi] of the 3x3 filter g = W[o][0..8][i]  (W [out_pad][9][in_pad], tap = r*3+s).
 // Training re-derives U from the master weights every step (the weights move); inference packs it once on the host.
+// chunked != 0: U in the order k_wino_fused streams it ([out_pad/64][in_pad/8][36][2 halves][64 lanes][4], see pack_conv),
+// so that the training step's forward and data-gradient convolutions run the fused kernel on the live weights.
 __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ W, float* __restrict__ U, int out_pad,
-                                                     int in_pad) {
+                                                     int in_pad, int chunked) {
     const int iq = in_pad >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)out_pad * iq) return;
@@ -182,14 +184,19 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const f32x4 u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
-            *reinterpret_cast<f32x4*>(U + (size_t)(i * 6 + j) * plane + (size_t)o * in_pad + i4) = u;
+            if (chunked) {
+                const int nl = o & 63, piece = (nl >> 5) * 64 + ((i4 >> 2) & 1) * 32 + (nl & 31);
+                *reinterpret_cast<f32x4*>(U + ((((size_t)(o >> 6) * (in_pad >> 3) + (i4 >> 3)) * 36 + (i * 6 + j)) * 128 + piece) * 4) = u;
+            } else {
+                *reinterpret_cast<f32x4*>(U + (size_t)(i * 6 + j) * plane + (size_t)o * in_pad + i4) = u;
+            }
         }
 }
 
-hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream) {
-    if (in_pad & 3) return hipErrorInvalidValue;
+hipError_t launch_wino_weights(const float* W, float* U, int out_pad, int in_pad, hipStream_t stream, int chunked) {
+    if ((in_pad & 3) || (chunked && ((in_pad & 7) || (out_pad & 63)))) return hipErrorInvalidValue;
     const long long total = (long long)out_pad * (in_pad >> 2);
-    hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, U, out_pad, in_pad);
+    hipLaunchKernelGGL(k_wino_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, W, U, out_pad, in_pad, chunked);
     return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 KCLASS_NAMES = ['conv_igemm', 'stem', 'se', 'combine', 'head', 'selfsim', 'channel',
-                'space', 'layout', 'score', 'wino', 'wino_fused']
+                'space', 'layout', 'score', 'wino', 'wino_fused', 'wgrad']
 
 
 class NativeLibraryMissing(RuntimeError):

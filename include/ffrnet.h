@@ -139,7 +139,8 @@ enum {
     FFR_KC_WINO = 10,       /* Winograd F(4x4,3x3) input / output transforms (HBM-bound) */
     FFR_KC_WINO_FUSED = 11, /* k_wino_fused: the 36 GEMMs + output transform of a Winograd conv (MFMA-bound; the
                                dominant kernel of the forward) */
-    FFR_KC_COUNT = 12
+    FFR_KC_WGRAD = 12,      /* k_wgrad: weight gradients of the training step as TN GEMMs (MFMA-bound) */
+    FFR_KC_COUNT = 13
 };
 typedef struct {
     int64_t launches;
@@ -159,8 +160,6 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "wino_fused" (1)      0: Winograd convolutions run as transform kernels around a batched GEMM (round-1 path)
  *   "wf_phased_maxk" (128) largest padded cin for which k_wino_fused transforms its own input
  *   "wf_minblocks" (200)  fewest 32-tile x 64-channel block tiles for which k_wino_fused is used
- *   "wf_dma" (1)          1: that in-kernel transform reads raw patches staged in LDS by LDS-DMA under the previous
- *                         phase's MFMAs (16-channel phases); 0: per-thread buffer loads (32-channel phases, round 2)
  *   "wf_halfblocks" (1)   1: below that limit the 16-tile block shape is used when it fills the chip
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
  *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD

@@ -114,7 +114,10 @@ int ffr_train_bucket_wait(ffr_handle* h, int i, void* stream);
 
 /* Options of the training state. "adam_step": sets Adam's step count (resume).  "winograd" (default 1): the 3x3 convolutions of the forward and of the data
  * gradient with >= 128 input channels run as Winograd F(4x4,3x3) (weights transformed on the device from the
- * live master weights at every use); 0 = direct implicit GEMM everywhere.  "fold_channel" (default 1): the
+ * live master weights at every use); 0 = direct implicit GEMM everywhere.  "fused" (default 1): those Winograd
+ * launches that fill the chip run k_wino_fused, the inference path's one-launch kernel (the weight transform emits
+ * U in the order that kernel streams); 0 = transform kernels around a batched GEMM; 2 = every Winograd launch fused
+ * (small test batches).  "fold_channel" (default 1): the
  * Linear(32,512) -> Linear(512,32) pairs of Conv4Channel (models/recnet.py:376-380) run as their 32x32 product
  * (exact algebra; gradients are mapped back onto the four tensors); 0 = the 512-wide intermediates are formed
  * as the reference does.                                                                                */

@@ -294,9 +294,10 @@ def test_train_backward_kink_free_network_both_modes(engine, specs):
             continue
         shp = tc['out_non'][i].shape
         stacked.append(torch.cat([a if a is not None else torch.zeros(shp), b if b is not None else torch.zeros(shp)]).cuda())
-    for mode in (0, 1):
+    for mode, fused in ((0, 1), (1, 0), (1, 2)):      # direct / Winograd as transform kernels + batched GEMM / Winograd in k_wino_fused
         engine.train_init(tc['sd_r'])
         engine.train_option('winograd', mode)
+        engine.train_option('fused', fused)
         engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
         engine.train_zero_grad()
         engine.train_backward(stacked)
@@ -307,7 +308,8 @@ def test_train_backward_kink_free_network_both_modes(engine, specs):
             # a BatchNorm bias in front of [identity -> conv -> BatchNorm] has a gradient that is zero up to rounding
             # (the next BatchNorm removes the shift): errors are taken relative to at least 1e-3
             e = ((got.double() - ref.double()).abs().max() / max(ref.abs().max().item(), 1e-3)).item()
-            assert e < (1e-4 if mode == 0 else 3e-4), (mode, k, e)
+            assert e < (1e-4 if mode == 0 else 3e-4), (mode, fused, k, e)
+    engine.train_option('fused', 1)
 
 
 def test_recnet_shell_train_branch_two_iterations(specs):
@@ -408,15 +410,20 @@ def test_training_full_size_properties(specs):
     eng = ffrnet_amd.Engine(0)
     eng.load_encoder(sd_e)
     first = []
-    for mode in (1, 1, 0):
+    for mode, fused in ((1, 1), (1, 1), (0, 1), (1, 0)):
         tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
         eng.train_option('winograd', mode)
+        eng.train_option('fused', fused)
         items = torch.stack(tr.step(non, ocl, label)).cpu()
         first.append((items, tr.flat_grads.clone()))
     assert torch.equal(first[0][0], first[1][0]) and torch.equal(first[0][1], first[1][1])       # same mode: bitwise
     assert torch.allclose(first[0][0], first[2][0], rtol=2e-4)                                   # Winograd vs direct
     l2 = ((first[0][1] - first[2][1]).norm() / first[2][1].norm()).item()
     assert l2 < 2e-2, l2          # whole flat gradient, kink noise included (256-image batch)
+    # the fused kernel and the transform-kernel form of the same Winograd arithmetic (summation order differs only)
+    assert torch.allclose(first[0][0], first[3][0], rtol=2e-5)
+    l2f = ((first[0][1] - first[3][1]).norm() / first[3][1].norm()).item()
+    assert l2f < 2e-2, l2f
     tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
     totals = []
     for _ in range(6):
