@@ -202,6 +202,34 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
     return half_n ? 2 : 1;
 }
 
+// True when the Winograd convolution (L on N x H x W) will run k_wino_fused over the WHOLE batch from a V that already
+// lies in winoV in fragment order (run_conv with wino_stage 2 / v_chunked): not the in-kernel transform, no split-off
+// remainder, scratch large enough.  run_conv applies the same tests.
+bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap) {
+    if (!L.wu || !L.wuc || !h->opt.wino || L.pad_mode != 0) return false;
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)N * th * tw;
+    const double x_bytes = 4.0 * N * H * W * in_pitch;
+    if (L.cin_pad <= h->opt.wf_phased_maxk && x_bytes <= 1073741824.0) return false;
+    const int choice = wino_fused_choice(h, L.cin_pad, L.cout_pad, T, x_bytes, -1);
+    if (choice == 0 || wino_chunked_floats(T, L.cin_pad) > wino_cap || T >= 0x7fffffffLL || in_pitch != L.cin_pad) return false;
+    const long long bt = ((T + 31) / 32) * (L.cout_pad / (choice == 2 ? 32 : 64));
+    const long long full = bt / h->num_cus * h->num_cus, rem = bt - full;
+    const bool tail_split = h->opt.wf_tailsplit != 0 && !h->opt.wf_trace;
+    if (tail_split && full > 0 && rem > 0 && rem * 4 <= h->num_cus) return false;
+    return true;
+}
+
+// conv L1 (3x3 / 1 / zero pad on N x H x W) may hand its output to conv L2 (same map) as a ready V written by its own epilogue
+// (k_wino_fused<0, ., 1>): both run k_wino_fused from V over the whole batch, L1's tile groups hold whole images, and L2 pads
+// with zeros.
+bool wino_epi_v_ok(const ffr_handle* h, const ConvW& L1, const ConvW& L2, int N, int H, int W, int in_pitch, size_t wino_cap) {
+    if (!h->opt.epi_v || L2.stride != 1 || L2.R != 3 || L2.pad_mode != 0 || L1.cout_pad != L2.cin_pad) return false;
+    const int th = (H + 3) / 4, tw = (W + 3) / 4, tiles_img = th * tw;
+    if (th != tw || tiles_img > 32 || 32 % tiles_img || (32 / tiles_img) * (4 * tw + 2) * (4 * tw + 2) * 32 > 36 * 32 * 32) return false;
+    return wino_accepts_ready_v(h, L1, N, H, W, in_pitch, wino_cap) && wino_accepts_ready_v(h, L2, N, H, W, L1.cout_pad, wino_cap);
+}
+
 // Tile shape and block count of one launch.
 //  * large problems (at least a quarter of a tile of K-tiles per persistent block at 128x128):
 //    persistent stream-K over 256 CUs x resident blocks, biggest tile that divides cout (tile
@@ -343,14 +371,17 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         const long long mbn = (T + 31) / 32;
         const int nbn = L.cout_pad / (half_n ? 32 : 64);
         const long long block_tiles = mbn * nbn;
-        if (choice != 0 && L.wuc && c.wino_stage == 0 && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
+        const bool v_ready = c.wino_stage == 2 && c.v_chunked;
+        if (v_ready && !wino_accepts_ready_v(h, L, c.N, c.H, c.W, c.in_pitch, c.wino_cap))
+            return fail(h, FFR_ERR_STATE, "a ready V was announced for a convolution that cannot take it");
+        if (choice != 0 && L.wuc && (c.wino_stage == 0 || v_ready) && (phased || wino_chunked_floats(T, L.cin_pad) <= c.wino_cap) && T < 0x7fffffffLL) {
             // The launch runs in rounds of one block tile per CU, all of the same duration: a last round with few block
             // tiles leaves most of the chip idle for a whole block time (784 block tiles of a 128 -> 128 layer at 28x28 =
             // 3.06 rounds took 4: 245 us where 3 rounds are 178).  When the last round would be less than a quarter full,
             // the images whose block tiles fill whole rounds run here and the remaining few images (2 % of the batch) on the
             // transform-kernel + batched-GEMM path, whose small tiles spread over every CU.  Option wf_tailsplit = 0: off.
             const long long full = block_tiles / h->num_cus * h->num_cus, rem = block_tiles - full;
-            if (tail_split && c.wino_mode < 0 && full > 0 && rem > 0 && rem * 4 <= h->num_cus) {
+            if (tail_split && c.wino_mode < 0 && full > 0 && rem > 0 && rem * 4 <= h->num_cus && !v_ready) {
                 const int tiles_img = th * tw;
                 // (leaving 8..64 CUs without a block tile in the last round for the remainder's kernels did not help: 16.78 ms
                 // per forward with none, 16.79 / 16.81 / 16.83 / 17.04 with 8 / 16 / 32 / 64)
@@ -381,7 +412,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 }
             }
             if (c.took_wino) *c.took_wino = true;
-            if (!phased) {
+            if (!phased && !v_ready) {
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + 36.0 * T * L.cin_pad));
                 HIPCK(h, launch_wino_in_chunked(c.x, c.winoV, c.N, c.H, c.W, c.in_pitch, L.cin_pad, L.pad_mode, st));
             }
@@ -392,6 +423,10 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // batch 256); FFR_WF_MAPV=0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
             f.map_v = h->opt.wf_mapv ? 1 : 0;
             f.half_n = half_n ? 1 : 0;
+            if (c.v2out) {
+                if (phased) return fail(h, FFR_ERR_STATE, "epilogue V output needs the V-fed form of k_wino_fused");
+                f.v2out = c.v2out; f.v2_nkc = L.cout_pad / 8;
+            }
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
             f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
@@ -617,6 +652,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
     float* cur = w.bufA;
     float* nxt = w.bufB;
     int ch = H, cw = W, cc = 64;
+    bool v_ready = false;                 // winoV holds the transform of `cur` in the order k_wino_fused streams
     for (int i = 0; i < n_blocks; ++i) {
         const Block& b = h->blocks[i];
         const int ho = ch / b.stride, wo = cw / b.stride;
@@ -627,13 +663,18 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         // conv1 -> conv2 without the activation round trip when both run as Winograd on a map of <= 4x4 tiles
         const bool oi_fuse = h->opt.wino_oi != 0;
         const long long Tt = (long long)N * ((ch + 3) / 4) * ((cw + 3) / 4);
-        bool chained = false;
+        bool chained = false, chained_candidate = false;
         const bool fused_on = h->opt.wino_fused != 0;
         if (!fused_on && oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
             wino_out_in_supported(ch, cw, b.c1.cout_pad) && (size_t)36 * Tt * b.c1.cout_pad <= w.wino_cap &&
             (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
             c1.wino_stage = 1; c1.took_wino = &chained;
+            chained_candidate = true;
         }
+        if (v_ready) { c1.wino_stage = 2; c1.v_chunked = true; }
+        // conv1 -> conv2 in the transform domain: conv1's epilogue writes conv2's V (into the second scratch), t1 never exists
+        const bool epi_v = !chained_candidate && b.stride == 1 && wino_epi_v_ok(h, b.c1, b.c2, N, ch, cw, b.cin, w.wino_cap);
+        if (epi_v) c1.v2out = w.winoM;
         RC(run_conv(h, b.c1, c1, st));
         if (chained) {
             Scope s(h, st, FFR_KC_WINO, 0, 4.0 * 72.0 * Tt * b.c1.cout_pad);
@@ -653,6 +694,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
         if (chained) c2.wino_stage = 2;
+        if (epi_v) { c2.winoV = w.winoM; c2.winoM = w.winoV; c2.wino_stage = 2; c2.v_chunked = true; }
         RC(run_conv(h, b.c2, c2, st));
         {
             const double e = (double)N * ho * wo * b.depth;
@@ -669,7 +711,16 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             RC(run_conv(h, b.sc, cs, st));
             scp = w.sc;
         }
-        {
+        // the next unit's conv1 reads this unit's output through its Winograd transform: when that conv runs k_wino_fused
+        // from V (cin >= 256: stage 3 and 4), the combine writes V itself and the separate transform pass is skipped
+        v_ready = false;
+        if (h->opt.combine_v && i + 1 < n_blocks && (scp || b.stride == 1) && combine_in_c_supported(ho, wo, b.depth) &&
+            wino_accepts_ready_v(h, h->blocks[i + 1].c1, N, ho, wo, b.depth, w.wino_cap)) {
+            const double e = (double)N * ho * wo * b.depth;
+            Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 4.0 * (3.0 * e + 36.0 * N * ((ho + 3) / 4) * ((wo + 3) / 4) * b.depth));
+            HIPCK(h, launch_combine_in_c(w.res, w.scale, scp ? scp : cur, nxt, w.winoV, N, ho, wo, b.depth, st));
+            v_ready = true;
+        } else {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 12.0 * e);
             HIPCK(h, launch_combine(w.res, w.scale, scp, cur, nxt, N, ho, wo, b.depth, b.stride, st));
@@ -1147,7 +1198,7 @@ const OptEntry OPTIONS[] = {
     {"wf_mapv", &Options::wf_mapv, nullptr, 0, 1}, {"wino_slice_mb", nullptr, &Options::wino_slice_mb, 0, 1LL << 20},
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
     {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
-    {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"s2_poly", &Options::s2_poly, nullptr, 0, 1},
+    {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1}, {"epi_v", &Options::epi_v, nullptr, 0, 1},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {

@@ -147,6 +147,100 @@ hipError_t launch_wino_in_chunked(const float* x, float* Vc, int N, int H, int W
     return hipGetLastError();
 }
 
+// ---- bottleneck combine + input transform of the next conv1 in one pass -------------------------------------------
+// x = res * scale[n] + shortcut (pretrain/model_ir_se50.py:73-76) is needed twice: as the next unit's shortcut (NHWC `out`)
+// and, transformed, as the V operand of the next unit's conv1.  k_combine wrote it and k_wino_in_c read it straight back.
+// Here a block owns the 32 tiles of one tile group = whole images (2 images of 14x14, 8 of 7x7) x 32 channels: it reads
+// res and the shortcut ONCE with full 128-byte lines, writes `out` the same way and keeps x in LDS (50 KB), from where
+// every tile takes its 6x6 patch (zero outside the image) for B^T d B; a V store covers, per (K chunk, k half), 8 tiles x
+// 16 B = one full line of the fragment image.  grid (ceil(T / 32), C / 32).
+// (A first version without LDS -- every thread loading its own patch of res and shortcut, 2.25x redundant through L2 --
+// ran at 3.7 TB/s: 81 us where k_combine + k_wino_in_c take 34 + 38.)
+constexpr int CIC_MAXPX = 392;          // pixels of a tile group's images: 2 x 14 x 14 = 8 x 7 x 7
+__global__ __launch_bounds__(256) void k_combine_in_c(const float* __restrict__ res, const float* __restrict__ scale,
+                                                     const float* __restrict__ sh, float* __restrict__ out,
+                                                     float* __restrict__ Vc, int N, int H, int W, int C, int nkc, int th, int tw) {
+    __shared__ __attribute__((aligned(16))) float s_x[CIC_MAXPX * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mb = blockIdx.x;
+    const int tiles_img = th * tw, ipg = 32 / tiles_img, HW = H * W;
+    const int n_first = mb * ipg;
+    const int n_imgs = N - n_first < ipg ? N - n_first : ipg;
+    const int cb = blockIdx.y * 32;
+    // phase 1: x of the group's images, 8 lanes per pixel line
+    {
+        const int q4 = (tid & 7) * 4;
+        const int npx = n_imgs * HW;
+        for (int p = tid >> 3; p < npx; p += 32) {
+            const int il = p / HW;
+            const size_t off = ((size_t)n_first * HW + p) * C + cb + q4;
+            const f32x4 sv = *reinterpret_cast<const f32x4*>(scale + (size_t)(n_first + il) * C + cb + q4);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(res + off) * sv + *reinterpret_cast<const f32x4*>(sh + off);
+            *reinterpret_cast<f32x4*>(out + off) = x;
+            *reinterpret_cast<f32x4*>(s_x + p * 32 + q4) = x;
+        }
+    }
+    __syncthreads();
+    // phase 2: tile 8 wave + (lane >> 3), channel quad lane & 7
+    const int tl = 8 * wave + (lane >> 3), quad = lane & 7;
+    const int kc = blockIdx.y * 4 + (quad >> 1), hf = quad & 1;
+    float* vout = Vc + (((size_t)mb * nkc + kc) * 36) * 256 + (hf * 32 + tl) * 4;
+    const int il = tl / tiles_img, tr = tl - il * tiles_img;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (il >= n_imgs) {
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(vout + xi * 256) = zero4;
+        return;
+    }
+    const int ty = tr / tw, tx = tr - ty * tw;
+    const int h0 = ty * 4 - 1, w0 = tx * 4 - 1;
+    const float* xi_base = s_x + il * HW * 32 + quad * 4;
+    f32x4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int hi = h0 + i;
+        const bool okh = (unsigned)hi < (unsigned)H;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int wi = w0 + j;
+            d[i][j] = zero4;
+            if (okh && (unsigned)wi < (unsigned)W) d[i][j] = *reinterpret_cast<const f32x4*>(xi_base + (hi * W + wi) * 32);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 col[6], v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+        bt6v(col, v);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i][j] = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 v[6];
+        bt6v(d[i], v);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (i * 6 + j) * 256) = v[j];
+    }
+}
+
+// tile groups must hold whole images: 32 % (tiles per image) == 0 and at most CIC_MAXPX pixels per group
+bool combine_in_c_supported(int H, int W, int C) {
+    const int tiles_img = ((H + 3) / 4) * ((W + 3) / 4);
+    return C % 32 == 0 && tiles_img <= 32 && 32 % tiles_img == 0 && (32 / tiles_img) * H * W <= CIC_MAXPX;
+}
+
+hipError_t launch_combine_in_c(const float* res, const float* scale, const float* sh, float* out, float* Vc, int N, int H,
+                               int W, int C, hipStream_t stream) {
+    if (!combine_in_c_supported(H, W, C)) return hipErrorInvalidValue;
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)N * th * tw;
+    const dim3 grid((unsigned)((T + 31) / 32), C / 32);
+    hipLaunchKernelGGL(k_combine_in_c, grid, dim3(256), 0, stream, res, scale, sh, out, Vc, N, H, W, C, C / 8, th, tw);
+    return hipGetLastError();
+}
+
 // s_waitcnt vmcnt(n) for a value that is a constant only after unrolling
 __device__ __forceinline__ void wait_vmcnt(int n) {
     switch (n) {
@@ -175,7 +269,12 @@ constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias 
 // NT = 32-channel halves per block: 2 = the 32-tile x 64-channel block tile; 1 = 32 tiles x 32 channels (half the
 // accumulators and half the work per block: twice as many blocks for launches that would leave CUs idle or run a
 // nearly empty last round -- small batches, stage 4 and RecNet at 128 images per GPU).
-template <int MODE, int NT>
+// EPI = 1 (MODE 0 only, maps whose tile groups hold whole images: 14x14, 7x7): the output is the input of another zero-padded
+// 3x3 Winograd convolution (conv1 -> conv2 of a bottleneck) and nothing else reads it: the epilogue applies that
+// convolution's INPUT transform to its own output tiles -- their 6x6 patches lie inside the block's images, which it
+// assembles in LDS (with a zero border) where the product buffer E was -- and writes V in fragment order.  The activation
+// itself and the separate transform pass (k_wino_in_c) never exist.
+template <int MODE, int NT, int EPI>
 __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     constexpr bool PHASED = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -457,6 +556,13 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         // one (tile, 4 channels) per thread: a wave-instruction reads / stores 8 tiles x 128 bytes
         const int tl = (lane >> 3) + 8 * wave;
         const int vrc = s_tile[tl * 8 + 1];
+        f32x4 yv[EPI == 1 ? 4 : 1][EPI == 1 ? 4 : 1];
+        if constexpr (EPI == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) yv[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         if (vrc != 0) {                                                 // else: tile beyond T
             const int pix0 = s_tile[tl * 8 + 0];
             const int vr = vrc & 0xff, vc = vrc >> 8;
@@ -502,6 +608,19 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                     for (int jj = 0; jj < 4; ++jj) bs[i][jj] = *reinterpret_cast<const f32x4*>(s_bias + rc[i] + cc[jj] + cl);
             }
             f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == 1) {
+                // keep the activation (bias, PReLU; zero outside the map = the consumer's zero padding) for the LDS image
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        f32x4 v = y[i][jj] + bs[i][jj];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f) + slope[c] * fminf(v[c], 0.f);
+                        const float keep = (i < vr && jj < vc) ? 1.f : 0.f;
+                        yv[i][jj] = v * keep;
+                    }
+            } else
             if (vec4 && cg + 3 < a.cout_store) {
                 // Branch-free stores: pixel (i, jj) of a tile that hangs over the map's edge is redirected to the tile's
                 // last valid row / column, and the pixels are stored in DESCENDING order: the stray value lands first,
@@ -563,6 +682,50 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)t * a.cout_pad + cg) = psum;
             }
         }
+        if constexpr (EPI == 1) {
+            __syncthreads();                                // every thread has taken its products out of E
+            // the block's images with a one-pixel zero border: Y[image][P][P][32 channels], P = 4 tw + 2
+            const int P = 4 * a.tw + 2, tiles_img = a.th * a.tw, ipg = 32 / tiles_img;
+            for (int i = tid; i < ipg * 4 * (P - 1) * 8; i += 256) {          // the border ring
+                const int q = i & 7, r = (i >> 3) % (4 * (P - 1)), il = (i >> 3) / (4 * (P - 1));
+                const int side = r / (P - 1), k = r - side * (P - 1);
+                const int yy = side == 0 ? 0 : (side == 1 ? k : (side == 2 ? P - 1 : k + 1));
+                const int xx = side == 0 ? k : (side == 1 ? P - 1 : (side == 2 ? k + 1 : 0));
+                *reinterpret_cast<f32x4*>(smem + ((il * P + yy) * P + xx) * 32 + 4 * q) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const int il = tl / tiles_img, tr = tl - il * tiles_img;
+            const int ty = tr / a.tw, tx = tr - ty * a.tw;
+            float* const yb = smem + ((il * P + 4 * ty) * P + 4 * tx) * 32 + 4 * cq;        // the tile's patch origin (border included)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(yb + ((i + 1) * P + jj + 1) * 32) = yv[i][jj];
+            __syncthreads();
+            // V = B^T d B of the tile's patch, four channels; a wave store covers, per (K chunk, k half), 8 tiles x 16 B
+            f32x4 d[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(yb + (i * P + j) * 32);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x4 col[6], v[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+                bt6v(col, v);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d[i][j] = v[i];
+            }
+            const int cch = n0 + nt * 32 + 4 * cq;
+            float* const vout = a.v2out + (((size_t)mb * a.v2_nkc + (cch >> 3)) * 36) * 256 + (((cch >> 2) & 1) * 32 + tl) * 4;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 v[6];
+                bt6v(d[i], v);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (i * 6 + j) * 256) = v[j];
+            }
+        }
         if (FFR_TRACE_ON(a.trace) && !PHASED) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
@@ -581,8 +744,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 }
 
 hipError_t wino_fused_init() {
-    const void* fns[4] = {(const void*)k_wino_fused<0, 2>, (const void*)k_wino_fused<1, 2>,
-                          (const void*)k_wino_fused<0, 1>, (const void*)k_wino_fused<1, 1>};
+    const void* fns[6] = {(const void*)k_wino_fused<0, 2, 0>, (const void*)k_wino_fused<1, 2, 0>,
+                          (const void*)k_wino_fused<0, 1, 0>, (const void*)k_wino_fused<1, 1, 0>,
+                          (const void*)k_wino_fused<0, 2, 1>, (const void*)k_wino_fused<0, 1, 1>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -610,12 +774,20 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
     a.nbn = a.cout_pad / (a.half_n ? 32 : 64);
     const dim3 grid(wf_grid(a.mbn, a.nbn, a.map_v));
     if (a.Vc) {
-        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<0, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((k_wino_fused<0, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.v2out) {
+            const int tiles_img = a.th * a.tw;
+            if (tiles_img > 32 || 32 % tiles_img || (32 / tiles_img) * (4 * a.tw + 2) * (4 * a.tw + 2) * 32 > WF_EPI_FLOATS ||
+                a.th != a.tw || a.resid || a.tile_sums || (a.flags & 1) || a.v2_nkc * 8 != a.cout_pad)
+                return hipErrorInvalidValue;
+            if (a.half_n) hipLaunchKernelGGL((k_wino_fused<0, 1, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+            else hipLaunchKernelGGL((k_wino_fused<0, 2, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        } else if (a.half_n) hipLaunchKernelGGL((k_wino_fused<0, 1, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((k_wino_fused<0, 2, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     } else {
         if (!a.x || a.nkc % 4 || a.x_bytes == 0 || a.x_bytes > 0x40000000u) return hipErrorInvalidValue;
-        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<1, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((k_wino_fused<1, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.v2out) return hipErrorInvalidValue;
+        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<1, 1, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((k_wino_fused<1, 2, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }

@@ -164,7 +164,11 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
  *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
  *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
- *   "s2_poly" (1)         1: stride-2 3x3 convolutions run as polyphase Winograd where packed for it
+ *   "epi_v" (1)           1: conv1 of a bottleneck on a 14x14 / 7x7 map writes conv2's Winograd input transform V from its
+ *                         own epilogue (k_wino_fused<0,.,1>): neither the activation between them nor k_wino_in_c exists
+ *   "combine_v" (1)       1: a bottleneck's combine (res * scale + shortcut) also writes the Winograd transform V of its
+ *                         output when the next unit's conv1 runs k_wino_fused from V (stage 3 / 4): k_combine_in_c
+ *                         replaces k_combine + k_wino_in_c
  *   "gemm_stream" (1), "gs_tile" (0), "sk_minunits" (18), "wino_oi" (1), "wino_slice_mb" (0)   round-1 path details
  *   "wf_trace", "igemm_trace" (0)   per-launch phase stamps on stderr; only in a -DFFR_TRACE build (tools/trace_build.py),
  *                                    the shipped library returns FFR_ERR_UNSUPPORTED
