@@ -123,26 +123,51 @@ def so_sha256():
     return h.hexdigest()
 
 
-def pmc_traffic(sha):
-    """HBM bytes per launch of the dominant kernel and per step, from the committed rocprofv3 --pmc passes
-    (tools/pmc_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md
-    prescribes for 16-B-per-lane streams on gfx950).  PMC counters cannot be read from inside this process, so
-    the file carries the sha256 of the library it was measured with: a different build gets no traffic figure."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except Exception:
-        return None
-    if d.get('so_sha256') != sha:
-        return {'hbm_bytes_per_launch': None,
-                'note': 'profiles/r02_pmc_hbm_traffic.json was measured with another build of libffrnet_hip.so '
-                        '(sha256 %s...): re-run tools/pmc_bench.sh' % str(d.get('so_sha256'))[:12]}
-    return {'hbm_bytes_per_launch': d['dominant']['hbm_bytes_per_launch'],
-            'launches_per_step': d['dominant']['launches_per_step'],
-            'hbm_gb_per_step_all_kernels': d['gb_per_step'],
-            'source': 'profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same build: sha256 %s...)'
-                      % sha[:12]}
+def pmc_traffic(sha, live=True):
+    """HBM bytes per launch of the dominant kernel and per step from rocprofv3 --pmc passes (tools/pmc_bench.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane
+    streams on gfx950).  PMC counters cannot be read from inside this process: the committed summary of the round
+    (profiles/r*_pmc_hbm_traffic.json) carries the sha256 of the library it was measured with and is used when that is
+    the library loaded here; for any other build the passes are run now, as child processes (about two minutes), so a
+    rebuilt library never silently loses the figure."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if d.get('so_sha256') == sha and 'dominant' in d:
+            rel = os.path.relpath(path, ROOT)
+            return {'hbm_bytes_per_launch': d['dominant']['hbm_bytes_per_launch'],
+                    'launches_per_step': d['dominant']['launches_per_step'],
+                    'hbm_gb_per_step_all_kernels': d['gb_per_step'],
+                    'mfma_busy_frac_of_kernel_time': d['dominant'].get('mfma_busy_frac_of_kernel_time'),
+                    'source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same build: sha256 %s...)' % (rel, sha[:12])}
+    import shutil
+    if live and shutil.which('rocprofv3') and os.environ.get('FFR_BENCH_LIVE_PMC', '1') != '0':
+        try:
+            t0 = time.perf_counter()
+            env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+            for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+                env.pop(k, None)
+            subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_bench.sh')], env=env, cwd=ROOT, timeout=600,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'pmc_bench', 'summary.json')) as f:
+                d = json.load(f)
+            if d.get('so_sha256') == sha and 'dominant' in d:
+                return {'hbm_bytes_per_launch': d['dominant']['hbm_bytes_per_launch'],
+                        'launches_per_step': d['dominant']['launches_per_step'],
+                        'hbm_gb_per_step_all_kernels': d['gb_per_step'],
+                        'mfma_busy_frac_of_kernel_time': d['dominant'].get('mfma_busy_frac_of_kernel_time'),
+                        'source': 'measured in this run: tools/pmc_bench.sh as child processes (rocprofv3 --pmc, %.0f s); no '
+                                  'committed summary matches this build (sha256 %s...)' % (time.perf_counter() - t0, sha[:12])}
+        except Exception as e:          # no profiler, no permission, timeout: say so instead of inventing a number
+            return {'hbm_bytes_per_launch': None, 'note': 'no committed PMC summary matches this build (sha256 %s...) and the '
+                    'live rocprofv3 --pmc passes failed: %s' % (sha[:12], str(e)[:200])}
+    return {'hbm_bytes_per_launch': None,
+            'note': 'no profiles/r*_pmc_hbm_traffic.json was measured with this build of libffrnet_hip.so (sha256 %s...): '
+                    're-run tools/pmc_bench.sh' % sha[:12]}
 
 
 def host_cores():

@@ -220,16 +220,6 @@ bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int
     return true;
 }
 
-// conv L1 (3x3 / 1 / zero pad on N x H x W) may hand its output to conv L2 (same map) as a ready V written by its own epilogue
-// (k_wino_fused<0, ., 1>): both run k_wino_fused from V over the whole batch, L1's tile groups hold whole images, and L2 pads
-// with zeros.
-bool wino_epi_v_ok(const ffr_handle* h, const ConvW& L1, const ConvW& L2, int N, int H, int W, int in_pitch, size_t wino_cap) {
-    if (!h->opt.epi_v || L2.stride != 1 || L2.R != 3 || L2.pad_mode != 0 || L1.cout_pad != L2.cin_pad) return false;
-    const int th = (H + 3) / 4, tw = (W + 3) / 4, tiles_img = th * tw;
-    if (th != tw || tiles_img > 32 || 32 % tiles_img || (32 / tiles_img) * (4 * tw + 2) * (4 * tw + 2) * 32 > 36 * 32 * 32) return false;
-    return wino_accepts_ready_v(h, L1, N, H, W, in_pitch, wino_cap) && wino_accepts_ready_v(h, L2, N, H, W, L1.cout_pad, wino_cap);
-}
-
 // Tile shape and block count of one launch.
 //  * large problems (at least a quarter of a tile of K-tiles per persistent block at 128x128):
 //    persistent stream-K over 256 CUs x resident blocks, biggest tile that divides cout (tile
@@ -423,10 +413,6 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // batch 256); FFR_WF_MAPV=0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
             f.map_v = h->opt.wf_mapv ? 1 : 0;
             f.half_n = half_n ? 1 : 0;
-            if (c.v2out) {
-                if (phased) return fail(h, FFR_ERR_STATE, "epilogue V output needs the V-fed form of k_wino_fused");
-                f.v2out = c.v2out; f.v2_nkc = L.cout_pad / 8;
-            }
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
             f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
@@ -663,18 +649,14 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         // conv1 -> conv2 without the activation round trip when both run as Winograd on a map of <= 4x4 tiles
         const bool oi_fuse = h->opt.wino_oi != 0;
         const long long Tt = (long long)N * ((ch + 3) / 4) * ((cw + 3) / 4);
-        bool chained = false, chained_candidate = false;
+        bool chained = false;
         const bool fused_on = h->opt.wino_fused != 0;
         if (!fused_on && oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
             wino_out_in_supported(ch, cw, b.c1.cout_pad) && (size_t)36 * Tt * b.c1.cout_pad <= w.wino_cap &&
             (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
             c1.wino_stage = 1; c1.took_wino = &chained;
-            chained_candidate = true;
         }
         if (v_ready) { c1.wino_stage = 2; c1.v_chunked = true; }
-        // conv1 -> conv2 in the transform domain: conv1's epilogue writes conv2's V (into the second scratch), t1 never exists
-        const bool epi_v = !chained_candidate && b.stride == 1 && wino_epi_v_ok(h, b.c1, b.c2, N, ch, cw, b.cin, w.wino_cap);
-        if (epi_v) c1.v2out = w.winoM;
         RC(run_conv(h, b.c1, c1, st));
         if (chained) {
             Scope s(h, st, FFR_KC_WINO, 0, 4.0 * 72.0 * Tt * b.c1.cout_pad);
@@ -694,7 +676,6 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
         if (chained) c2.wino_stage = 2;
-        if (epi_v) { c2.winoV = w.winoM; c2.winoM = w.winoV; c2.wino_stage = 2; c2.v_chunked = true; }
         RC(run_conv(h, b.c2, c2, st));
         {
             const double e = (double)N * ho * wo * b.depth;
@@ -1198,7 +1179,7 @@ const OptEntry OPTIONS[] = {
     {"wf_mapv", &Options::wf_mapv, nullptr, 0, 1}, {"wino_slice_mb", nullptr, &Options::wino_slice_mb, 0, 1LL << 20},
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
     {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
-    {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1}, {"epi_v", &Options::epi_v, nullptr, 0, 1},
+    {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {

@@ -59,7 +59,6 @@ struct Options {
     int sk_minunits = 18;         // smallest number of K-tiles a stream-K block may own
     int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
     int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
-    int epi_v = 1;                // 1: conv1 of a stage-3/4 bottleneck writes conv2's V from its epilogue (no activation, no transform pass)
     int combine_v = 1;            // 1: a bottleneck's combine also writes V for the next conv1 when that runs k_wino_fused from V
     int wf_trace = 0, igemm_trace = 0;   // -DFFR_TRACE builds only: per-launch phase stamps on stderr (synchronises)
 };
@@ -196,7 +195,6 @@ struct ConvCall {
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
     int wino_mode = -1;                            // -1 auto (env FFR_WINO; fused kernel when the launch fills the chip), 0 never, 1 Winograd, fused kernel when packed for it, 2 Winograd, transform kernels + batched GEMM
     int wino_stage = 0;                            // 0 whole conv; 1 stop after the GEMM (M stays in winoM); 2 V is ready in winoV
-    float* v2out = nullptr;                        // fused kernel only (wino_epi_v_ok): the output leaves as the V of the next zero-padded 3x3 convolution
     bool v_chunked = false;                        // with wino_stage 2: V is in the K-chunked fragment order of k_wino_fused (wino_accepts_ready_v)
     bool* took_wino = nullptr;                     // set to true when the Winograd path ran
     float* tile_sums = nullptr;                    // Winograd path only: per-tile sums of the stored outputs [T][cout_pad]
@@ -204,7 +202,6 @@ struct ConvCall {
 };
 
 int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long T, double x_bytes, int wino_mode);
-bool wino_epi_v_ok(const ffr_handle* h, const ConvW& L1, const ConvW& L2, int N, int H, int W, int in_pitch, size_t wino_cap);
 bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap);
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st);
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st);

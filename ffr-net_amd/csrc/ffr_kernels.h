@@ -88,7 +88,6 @@ struct WinoFusedArgs {
     const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
     int N, H, W, nkc;                       // nkc = cin_pad / 8
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
-    float* v2out; int v2_nkc;               // not null: instead of `out`, write the output's Winograd input transform (fragment order, v2_nkc = cout_pad / 8 K chunks)
     int half_n;                             // 1: blocks of 32 tiles x 32 channels (k_wino_fused<., 1>) instead of 32 x 64
     int map_v;                              // block -> tile mapping: 1 = the channel groups of a tile group share an XCD (V from its L2)
     int th, tw, mbn, nbn;                   // filled by the launcher

@@ -269,12 +269,7 @@ constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias 
 // NT = 32-channel halves per block: 2 = the 32-tile x 64-channel block tile; 1 = 32 tiles x 32 channels (half the
 // accumulators and half the work per block: twice as many blocks for launches that would leave CUs idle or run a
 // nearly empty last round -- small batches, stage 4 and RecNet at 128 images per GPU).
-// EPI = 1 (MODE 0 only, maps whose tile groups hold whole images: 14x14, 7x7): the output is the input of another zero-padded
-// 3x3 Winograd convolution (conv1 -> conv2 of a bottleneck) and nothing else reads it: the epilogue applies that
-// convolution's INPUT transform to its own output tiles -- their 6x6 patches lie inside the block's images, which it
-// assembles in LDS (with a zero border) where the product buffer E was -- and writes V in fragment order.  The activation
-// itself and the separate transform pass (k_wino_in_c) never exist.
-template <int MODE, int NT, int EPI>
+template <int MODE, int NT>
 __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     constexpr bool PHASED = MODE != 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -556,13 +551,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         // one (tile, 4 channels) per thread: a wave-instruction reads / stores 8 tiles x 128 bytes
         const int tl = (lane >> 3) + 8 * wave;
         const int vrc = s_tile[tl * 8 + 1];
-        f32x4 yv[EPI == 1 ? 4 : 1][EPI == 1 ? 4 : 1];
-        if constexpr (EPI == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) yv[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
         if (vrc != 0) {                                                 // else: tile beyond T
             const int pix0 = s_tile[tl * 8 + 0];
             const int vr = vrc & 0xff, vc = vrc >> 8;
@@ -608,19 +596,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                     for (int jj = 0; jj < 4; ++jj) bs[i][jj] = *reinterpret_cast<const f32x4*>(s_bias + rc[i] + cc[jj] + cl);
             }
             f32x4 psum = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == 1) {
-                // keep the activation (bias, PReLU; zero outside the map = the consumer's zero padding) for the LDS image
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        f32x4 v = y[i][jj] + bs[i][jj];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f) + slope[c] * fminf(v[c], 0.f);
-                        const float keep = (i < vr && jj < vc) ? 1.f : 0.f;
-                        yv[i][jj] = v * keep;
-                    }
-            } else
             if (vec4 && cg + 3 < a.cout_store) {
                 // Branch-free stores: pixel (i, jj) of a tile that hangs over the map's edge is redirected to the tile's
                 // last valid row / column, and the pixels are stored in DESCENDING order: the stray value lands first,
@@ -682,50 +657,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                 *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)t * a.cout_pad + cg) = psum;
             }
         }
-        if constexpr (EPI == 1) {
-            __syncthreads();                                // every thread has taken its products out of E
-            // the block's images with a one-pixel zero border: Y[image][P][P][32 channels], P = 4 tw + 2
-            const int P = 4 * a.tw + 2, tiles_img = a.th * a.tw, ipg = 32 / tiles_img;
-            for (int i = tid; i < ipg * 4 * (P - 1) * 8; i += 256) {          // the border ring
-                const int q = i & 7, r = (i >> 3) % (4 * (P - 1)), il = (i >> 3) / (4 * (P - 1));
-                const int side = r / (P - 1), k = r - side * (P - 1);
-                const int yy = side == 0 ? 0 : (side == 1 ? k : (side == 2 ? P - 1 : k + 1));
-                const int xx = side == 0 ? k : (side == 1 ? P - 1 : (side == 2 ? k + 1 : 0));
-                *reinterpret_cast<f32x4*>(smem + ((il * P + yy) * P + xx) * 32 + 4 * q) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            const int il = tl / tiles_img, tr = tl - il * tiles_img;
-            const int ty = tr / a.tw, tx = tr - ty * a.tw;
-            float* const yb = smem + ((il * P + 4 * ty) * P + 4 * tx) * 32 + 4 * cq;        // the tile's patch origin (border included)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4*>(yb + ((i + 1) * P + jj + 1) * 32) = yv[i][jj];
-            __syncthreads();
-            // V = B^T d B of the tile's patch, four channels; a wave store covers, per (K chunk, k half), 8 tiles x 16 B
-            f32x4 d[6][6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) d[i][j] = *reinterpret_cast<const f32x4*>(yb + (i * P + j) * 32);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                f32x4 col[6], v[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) col[i] = d[i][j];
-                bt6v(col, v);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d[i][j] = v[i];
-            }
-            const int cch = n0 + nt * 32 + 4 * cq;
-            float* const vout = a.v2out + (((size_t)mb * a.v2_nkc + (cch >> 3)) * 36) * 256 + (((cch >> 2) & 1) * 32 + tl) * 4;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                f32x4 v[6];
-                bt6v(d[i], v);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (i * 6 + j) * 256) = v[j];
-            }
-        }
         if (FFR_TRACE_ON(a.trace) && !PHASED) se[2 * nt + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
@@ -744,9 +675,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 }
 
 hipError_t wino_fused_init() {
-    const void* fns[6] = {(const void*)k_wino_fused<0, 2, 0>, (const void*)k_wino_fused<1, 2, 0>,
-                          (const void*)k_wino_fused<0, 1, 0>, (const void*)k_wino_fused<1, 1, 0>,
-                          (const void*)k_wino_fused<0, 2, 1>, (const void*)k_wino_fused<0, 1, 1>};
+    const void* fns[4] = {(const void*)k_wino_fused<0, 2>, (const void*)k_wino_fused<1, 2>,
+                          (const void*)k_wino_fused<0, 1>, (const void*)k_wino_fused<1, 1>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -774,20 +704,12 @@ hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream) {
     a.nbn = a.cout_pad / (a.half_n ? 32 : 64);
     const dim3 grid(wf_grid(a.mbn, a.nbn, a.map_v));
     if (a.Vc) {
-        if (a.v2out) {
-            const int tiles_img = a.th * a.tw;
-            if (tiles_img > 32 || 32 % tiles_img || (32 / tiles_img) * (4 * a.tw + 2) * (4 * a.tw + 2) * 32 > WF_EPI_FLOATS ||
-                a.th != a.tw || a.resid || a.tile_sums || (a.flags & 1) || a.v2_nkc * 8 != a.cout_pad)
-                return hipErrorInvalidValue;
-            if (a.half_n) hipLaunchKernelGGL((k_wino_fused<0, 1, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
-            else hipLaunchKernelGGL((k_wino_fused<0, 2, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
-        } else if (a.half_n) hipLaunchKernelGGL((k_wino_fused<0, 1, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((k_wino_fused<0, 2, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<0, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((k_wino_fused<0, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     } else {
         if (!a.x || a.nkc % 4 || a.x_bytes == 0 || a.x_bytes > 0x40000000u) return hipErrorInvalidValue;
-        if (a.v2out) return hipErrorInvalidValue;
-        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<1, 1, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
-        else hipLaunchKernelGGL((k_wino_fused<1, 2, 0>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        if (a.half_n) hipLaunchKernelGGL((k_wino_fused<1, 1>), grid, dim3(256), WF_LDS_BYTES, stream, a);
+        else hipLaunchKernelGGL((k_wino_fused<1, 2>), grid, dim3(256), WF_LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }

@@ -164,8 +164,6 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
  *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
  *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
- *   "epi_v" (1)           1: conv1 of a bottleneck on a 14x14 / 7x7 map writes conv2's Winograd input transform V from its
- *                         own epilogue (k_wino_fused<0,.,1>): neither the activation between them nor k_wino_in_c exists
  *   "combine_v" (1)       1: a bottleneck's combine (res * scale + shortcut) also writes the Winograd transform V of its
  *                         output when the next unit's conv1 runs k_wino_fused from V (stage 3 / 4): k_combine_in_c
  *                         replaces k_combine + k_wino_in_c

@@ -648,8 +648,7 @@ def test_experiment_knobs_keep_parity(tmp_path):
     for name, knobs in (('mapv0', {'FFR_OPT_WF_MAPV': '0'}), ('notailsplit', {'FFR_OPT_WF_TAILSPLIT': '0'}),
                         ('sepool', {'FFR_OPT_SE_MAXTILES': '0'}), ('unfused', {'FFR_OPT_WINO_FUSED': '0'}),
                         ('phased256', {'FFR_OPT_WF_PHASED_MAXK': '256'}), ('direct', {'FFR_OPT_WINO': '0'}),
-                        ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nocombinev', {'FFR_OPT_COMBINE_V': '0'}), ('noepiv', {'FFR_OPT_EPI_V': '0'}),
-                        ('noepiv_nocombinev', {'FFR_OPT_EPI_V': '0', 'FFR_OPT_COMBINE_V': '0'}),
+                        ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nocombinev', {'FFR_OPT_COMBINE_V': '0'}),
                         ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'})):
         got = run(name, **knobs)
         for k in ('f_new', 'f'):

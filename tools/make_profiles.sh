@@ -1,24 +1,39 @@
 #!/bin/bash
-# Round-2 measurement artefacts (run via gpurun from the repo root; copy gpurun_out/r02/* into profiles/).
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02
-rm -rf $O; mkdir -p $O
-cd $R
-# PMC passes first: bench.py reads profiles/r02_pmc_hbm_traffic.json (hash-locked to this build) for roofline.traffic
-bash tools/pmc_bench.sh > /dev/null 2>&1
-cp $R/gpurun_out/pmc_bench/summary.json $O/r02_pmc_hbm_traffic.json
-mkdir -p $R/profiles && cp $O/r02_pmc_hbm_traffic.json $R/profiles/r02_pmc_hbm_traffic.json
-python3 bench.py > $O/r02_bench.json 2> $O/bench.err
-python3 bench.py --pairs-per-step 512 --no-cpu-baseline --no-secondary > $O/r02_bench_pairs512_1gpu.json 2>> $O/bench.err
-FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --pairs-per-step 512 --no-roofline --no-cpu-baseline > $O/r02_bench_selflaunch_2ranks_one_device.json 2>> $O/bench.err
-python3 tools/bench_train.py --cpu-baseline > $O/r02_train_step.json 2>> $O/bench.err
-FFR_WF_TRACE=1 python3 tools/wf_trace.py 2>&1 | grep "wf trace" > $O/r02_wino_fused_phase_trace.txt
-FFR_IGEMM_TRACE=1 python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > $O/r02_igemm_trace.txt
+# Measurement artefacts of one round (run via gpurun from the repo root):  bash tools/make_profiles.sh r03
+# Writes gpurun_out/<round>/<round>_*; the PMC summary is installed under profiles/ ONLY when every counter pass succeeded
+# and its so_sha256 is the hash of the library in the tree.
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the root of the snapshot)}"
+RD="${1:-r03}"
+R="$GRAFT_REPO_ROOT"
+O="$R/gpurun_out/$RD"
+rm -rf -- "$O"; mkdir -p -- "$O"
+cd -- "$R"
+SHA=$(sha256sum ffr-net_amd/libffrnet_hip.so | cut -d' ' -f1)
+# PMC passes first: bench.py reads profiles/<round>_pmc_hbm_traffic.json (hash-locked to this build) for roofline.traffic
+if bash tools/pmc_bench.sh > "$O/pmc_bench.log" 2>&1 && grep -q "\"so_sha256\": \"$SHA\"" "$R/gpurun_out/pmc_bench/summary.json"; then
+  cp -- "$R/gpurun_out/pmc_bench/summary.json" "$O/${RD}_pmc_hbm_traffic.json"
+  mkdir -p -- "$R/profiles" && cp -- "$O/${RD}_pmc_hbm_traffic.json" "$R/profiles/${RD}_pmc_hbm_traffic.json"
+else
+  echo "PMC pass failed or measured another build: profiles/${RD}_pmc_hbm_traffic.json NOT updated" | tee "$O/pmc_FAILED.txt"
+fi
+python3 bench.py > "$O/${RD}_bench.json" 2> "$O/bench.err" || echo "bench rc $?"
+for b in 128 64; do
+  python3 bench.py --batch $b --no-cpu-baseline --no-secondary > "$O/${RD}_bench_batch$b.json" 2>> "$O/bench.err" || echo "bench$b rc $?"
+done
+python3 bench.py --pairs-per-step 512 --no-cpu-baseline --no-secondary > "$O/${RD}_bench_pairs512_1gpu.json" 2>> "$O/bench.err" || true
+FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --pairs-per-step 512 --no-roofline --no-cpu-baseline 2>> "$O/bench.err" | grep '^{' > "$O/${RD}_bench_selflaunch_2ranks_gloo_one_device.json" || true
+python3 bench.py --workload train > "$O/${RD}_train_step.json" 2>> "$O/bench.err" || true
+python3 tools/wf_trace.py 2>&1 | grep "wf trace" > "$O/${RD}_wino_fused_phase_trace.txt" || true
+TRACE=igemm_trace python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > "$O/${RD}_igemm_trace.txt" || true
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/r02_bench_under_rocprof.json 2>/dev/null
-cp $O/prof/p_kernel_stats.csv $O/r02_bench_kernel_stats.csv
-python3 $R/tools/layer_times.py $O/prof/p_kernel_trace.csv > $O/r02_bench_layer_times.txt
-rocprofv3 --kernel-trace --stats -d $O/proft -o p --output-format csv -- python3 $R/tools/bench_train.py --steps 5 --warmup 2 > $O/r02_train_step_under_rocprof.json 2>/dev/null
-cp $O/proft/p_kernel_stats.csv $O/r02_train_step_kernel_stats.csv
-rm -rf $O/prof $O/proft
-ls -la $O
+for b in 256 128 64; do
+  rocprofv3 --kernel-trace --stats -d "$O/prof$b" -o p --output-format csv -- python3 "$R/bench.py" --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$O/${RD}_bench_batch${b}_under_rocprof.json" 2>/dev/null || true
+  cp -- "$O/prof$b/p_kernel_stats.csv" "$O/${RD}_bench_batch${b}_kernel_stats.csv" || true
+  python3 "$R/tools/layer_times.py" "$O/prof$b/p_kernel_trace.csv" > "$O/${RD}_bench_batch${b}_layer_times.txt" || true
+  rm -rf -- "$O/prof$b"
+done
+rocprofv3 --kernel-trace --stats -d "$O/proft" -o p --output-format csv -- python3 "$R/bench.py" --workload train --steps 5 --warmup 2 --no-roofline > "$O/${RD}_train_step_under_rocprof.json" 2>/dev/null || true
+cp -- "$O/proft/p_kernel_stats.csv" "$O/${RD}_train_step_kernel_stats.csv" || true
+rm -rf -- "$O/proft"
+ls -la -- "$O"

@@ -2,13 +2,15 @@
 # HBM traffic and matrix-core counters of one forward at batch 256 (run via gpurun; copy the summary into profiles/).
 # Separate --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2); FETCH_SIZE reads half of a
 # wide coalesced stream on gfx950 -> doubled below, WRITE_SIZE is exact.  The program follows `--` directly.
-R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/pmc_bench
-rm -rf $OUT; mkdir -p $OUT
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+R="$GRAFT_REPO_ROOT"
+OUT="$R/gpurun_out/pmc_bench"
+rm -rf -- "$OUT"; mkdir -p -- "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   d=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$d -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>$OUT/$d.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>"$OUT/$d.err"
 done
 python3 - <<PY
 import csv, glob, collections, json, hashlib
