@@ -34,11 +34,13 @@ def main():
     dev = torch.device('cuda', local)
     loader = [dict(img1=i1[s:s + a.batch].to(dev), img2=i2[s:s + a.batch].to(dev), label=lab[s:s + a.batch],
                    idx=torch.arange(s, min(s + a.batch, a.pairs))) for s in range(0, a.pairs, a.batch)]
-    pred_new, pred = ffrnet_amd.lfw.calculate_distance(loader, eng.embed)      # pairs sharded over the ranks, all-gather
+    # pairs sharded over the ranks, ONE all-gather of the embeddings per batch, scores and the 10-fold threshold protocol on
+    # the device (ffr_cosine_scores, ffr_lfw_fold_accuracy); with the two nn.Module shells the call is the reference's:
+    #     acc_new, acc = ffrnet_amd.lfw.get_avg_accuracy(encoder, recnet, data_loader)
+    acc_new, acc = ffrnet_amd.lfw.get_avg_accuracy(eng.embed, loader)
     if int(os.environ.get('RANK', '0')) == 0:
-        for name, p in (('f_new (RecNet)', pred_new), ('f (encoder)', pred)):
-            acc, _ = ffrnet_amd.lfw.get_accuracy_from_predicts(p, n_folds=10)
-            print('%-16s %d pairs, 10-fold accuracy %.4f' % (name, len(p), acc))
+        print('f_new (RecNet)   %d pairs, 10-fold accuracy %.4f' % (a.pairs, acc_new))
+        print('f (encoder)      %d pairs, 10-fold accuracy %.4f' % (a.pairs, acc))
     if world > 1:
         dist.destroy_process_group()
 

@@ -396,12 +396,6 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     chunk.template operator()<true>();
     } else if constexpr (MODE == 1) {
     // ---- PHASED: per 32 input channels: input transform -> LDS, then 4 K chunks with the A fragments from LDS ----
-    // Transform role of a thread, twice per phase (tile halves sh = 0, 1): tile 16 sh + 4 wave + (lane >> 4), channel
-    // pair lane & 15 of the phase's 32 channels.  Sixteen lanes read the whole 128-byte line of a pixel (with 32-byte
-    // pieces per lane pair the texture path, not HBM, set the pace: 20k cycles per phase on 56x56 maps); two channels
-    // per thread keep the 36 patch values at 72 registers (four channels = 144 registers spilled the accumulators of
-    // xi 8 into the MFMA chunks: 7.9k instead of 5.1k cycles per K chunk).
-    const int tp = lane & 15;
     f32x4 fu[9][NT];
     auto loadu = [&](int j, int part, const float* u) {
         fu[j][part] = *reinterpret_cast<const f32x4*>(u + j * 512 + part * 256);
@@ -423,74 +417,84 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     constexpr unsigned OOB = 0x40000000u;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const int nph = nkc >> 2;
+    // Transform role (round 3): ONE tile, FOUR channels per thread: tile 8 wave + (lane >> 3), channel quad lane & 7 of the
+    // phase's 32 channels: 36 buffer_load_dwordx4 per thread, 8 lanes read the whole 128-byte line of a pixel, whole
+    // 16-byte fragments go to LDS (36 ds_write_b128).  Round 2 gave a thread two tiles x two channels (72 8-byte loads,
+    // 16 lanes per pixel line): the same 1152 lines per phase cost 13.7-15.7k cycles instead of 11.8-13.4k on 56x56 /
+    // 112x112 maps and 10-11.7k instead of 8-9k on 28x28 (profiles/r03_exp_wf_wide_phase_trace.txt) -- the
+    // texture-address path charges per load instruction and 16-lane group, not per byte.
+    const int ttl = 8 * wave + (lane >> 3), tq = lane & 7;
+    // byte offsets of the 6 patch rows / columns of this thread's tile: computed before the first phase and again at the
+    // start of every phase's last K chunk (live from there to the next phase's loads; 24 such registers held across all
+    // MFMA chunks spilled accumulators in round 2)
+    unsigned ro[6], co[6];
+    auto offsets = [&]() {
+        const int tvrc = s_tile[ttl * 8 + 1];
+        const int tib = s_tile[ttl * 8 + 4], th0 = s_tile[ttl * 8 + 5], tw0 = s_tile[ttl * 8 + 6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            int hi = th0 + i, wi = tw0 + i;
+            bool rok, cok;
+            if (a.pad_mode == 1) {
+                hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi); if (hi < 0) hi = 0;
+                wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi); if (wi < 0) wi = 0;
+                rok = tvrc != 0; cok = true;
+            } else {
+                rok = tvrc != 0 && (unsigned)hi < (unsigned)a.H;
+                cok = (unsigned)wi < (unsigned)a.W;
+            }
+            ro[i] = rok ? (unsigned)((tib + hi * a.W) * a.in_pitch + tq * 4) * 4u : OOB;
+            co[i] = cok ? (unsigned)(wi * a.in_pitch) * 4u : OOB;
+        }
+    };
+    offsets();
+    // The first NPRE patch values of a phase (its first columns) are requested under the LAST K chunk of the phase before
+    // (its weight-fragment slots are dying there), so the memory latency of a phase's first access (~2.5k cycles from HBM)
+    // is paid under MFMAs and the column passes start at once.
+    constexpr int NPRE = 16;
+    f32x4 pre[NPRE];
+    auto load_px = [&](int idx, unsigned so) {          // patch value idx = j * 6 + i (column-major)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ro[idx % 6] + co[idx / 6], so, 0));
+    };
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) pre[k] = load_px(k, 0u);
     if (FFR_TRACE_ON(a.trace)) st1 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
     for (int ph = 0; ph < nph; ++ph) {
         unsigned long long tp0 = 0;
         if (FFR_TRACE_ON(a.trace)) tp0 = __builtin_amdgcn_s_memtime();
         const unsigned soff = (unsigned)(ph * 32) * 4u;                   // scalar: the phase's first channel
-            // byte offsets of the 6 patch rows / columns of this thread's two tiles (recomputed per phase: 24 registers held
-            // across the MFMA chunks spilled accumulators into them, measured 18.04 vs 17.85 ms per forward)
-        unsigned ro[2][6], co[2][6];
-    #pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-            const int ttl = 16 * sh + 4 * wave + (lane >> 4);
-            const int tvrc = s_tile[ttl * 8 + 1];
-            const int tib = s_tile[ttl * 8 + 4], th0 = s_tile[ttl * 8 + 5], tw0 = s_tile[ttl * 8 + 6];
-    #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                int hi = th0 + i, wi = tw0 + i;
-                bool rok, cok;
-                if (a.pad_mode == 1) {
-                    hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi); if (hi < 0) hi = 0;
-                    wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi); if (wi < 0) wi = 0;
-                    rok = tvrc != 0; cok = true;
-                } else {
-                    rok = tvrc != 0 && (unsigned)hi < (unsigned)a.H;
-                    cok = (unsigned)wi < (unsigned)a.W;
-                }
-                ro[sh][i] = rok ? (unsigned)((tib + hi * a.W) * a.in_pitch + tp * 2) * 4u : OOB;
-                co[sh][i] = cok ? (unsigned)(wi * a.in_pitch) * 4u : OOB;
+        {
+        f32x4 d[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)          // column by column: the first column pass starts under the other loads
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i][j] = j * 6 + i < NPRE ? pre[j * 6 + i] : load_px(j * 6 + i, soff);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {          // columns: d[.][j] <- B^T d[.][j]
+            f32x4 col[6], v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+            bt6t(col, v);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i][j] = v[i];
+        }
+        // quad tq = (chunk c = tq >> 1, half h = tq & 1): one whole fragment
+        float* vout = smem + (((tq >> 1) * 36) * 64 + (tq & 1) * 32 + (ttl & 24) + ((ttl + tq) & 7)) * 4;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {          // rows: V[i][.] = d[i][.] B, straight into the fragment image
+            f32x4 v[6];
+            bt6t(d[i], v);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (i * 6 + j) * 256) = v[j];
+            // the registers of the finished rows take this phase's first weight fragments
+            if (i >= 2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int part = 0; part < NT; ++part) loadu((i - 2) * 2 + q, part, up);
             }
         }
-        // -- input transform of channels [32 ph + 2 tp, +2) of this thread's two tiles: all 72 loads in flight first --
-        f32x2 d[2][6][6];
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-            for (int j = 0; j < 6; ++j)          // column by column: the first column pass starts under the other loads
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    d[sh][i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrsrc, ro[sh][i] + co[sh][j], soff, 0));
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-            const int ttl = 16 * sh + 4 * wave + (lane >> 4);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {          // columns: d[.][j] <- B^T d[.][j]
-                f32x2 col[6], v[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) col[i] = d[sh][i][j];
-                bt6t(col, v);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) d[sh][i][j] = v[i];
-            }
-            // pair tp = (chunk c = tp >> 2, half h = (tp >> 1) & 1, 8-byte half of the fragment tp & 1)
-            const int tq = tp >> 1;
-            float* vout = smem + (((tq >> 1) * 36) * 64 + (tq & 1) * 32 + (ttl & 24) + ((ttl + tq) & 7)) * 4 + (tp & 1) * 2;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {          // rows: V[i][.] = d[i][.] B, straight into the fragment image
-                f32x2 v[6];
-                bt6t(d[sh][i], v);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vout + (i * 6 + j) * 256) = v[j];
-                // the registers of the finished rows take this phase's first weight fragments
-                if (sh == 1 && i >= 2) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int part = 0; part < NT; ++part) loadu((i - 2) * 2 + q, part, up);
-                }
-            }
         }
         if (FFR_TRACE_ON(a.trace)) se[0] += __builtin_amdgcn_s_memtime() - tp0;       // diagnostics: transform (before the barrier)
         __syncthreads();
@@ -509,11 +513,17 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                     const int e = g / NT, nt = g % NT;
                     if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
                     else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
+                    if (c == 3 && j == 0 && g == 0) offsets();
                     if (g == 1) {              // both weight loads of the step in one MFMA gap (see the unphased loop)
 #pragma unroll
                         for (int part = 0; part < NT; ++part) {
                             if (j == 0) loadu(8, part, up);                                // xi 8 of this chunk
                             else if (c < 3) loadu(j - 1, part, up + 36 * 512);             // xi j-1 of the next chunk
+                        }
+                        // last chunk: two patch values of the next phase per step take the place of the weight loads
+                        if (c == 3 && j >= 1 && 2 * (j - 1) < NPRE) {      // (also behind the last phase: harmless, keeps `pre` dead in between)
+                            pre[2 * (j - 1)] = load_px(2 * (j - 1), soff + 128u);
+                            pre[2 * (j - 1) + 1] = load_px(2 * (j - 1) + 1, soff + 128u);
                         }
                     }
                     if (g == 2 * NT && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
