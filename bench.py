@@ -524,7 +524,7 @@ def main():
                           'convolution in one launch)',
                 'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                'traffic': pmc_traffic(sha),
+                'traffic': pmc_traffic(sha, live=(world == 1)),   # child profiler passes only when no other rank waits on this one
                 'note': 'achieved = FLOPs the matrix cores EXECUTED in k_wino_fused (2*36*tiles*cin*cout, padding '
                         'included) / its hipEvent time; the algorithmic direct-convolution FLOPs of those layers are '
                         '4x (3.06x on 7x7 maps) larger: effective_tflops_algorithmic',

@@ -410,7 +410,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             f.Vc = phased ? nullptr : c.winoV; f.x = c.x; f.x_bytes = phased ? (unsigned)x_bytes : 0u; f.in_pitch = c.in_pitch; f.pad_mode = L.pad_mode;
             // block -> tile mapping: the channel groups of a tile group next to each other on ONE XCD (V is fetched into that
             // L2 once instead of once per channel group: 59.5 -> 45.7 GB fetched + written per forward, 17.53 -> 17.32 ms at
-            // batch 256); FFR_WF_MAPV=0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
+            // batch 256); option wf_mapv = 0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
             f.map_v = h->opt.wf_mapv ? 1 : 0;
             f.half_n = half_n ? 1 : 0;
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmArgs a) {
     const long long G = U / a.granule;      // granule = 1, or nkt when tiles are not cut (tiny K)
     long long u = (long long)blockIdx.x * G / gridDim.x * a.granule;
     const long long uend = (long long)(blockIdx.x + 1) * G / gridDim.x * a.granule;
-    unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_seg = 0, tr_t = 0, tr_rt0 = 0;   // FFR_IGEMM_TRACE only
+    unsigned long long tr_acc[6] = {0, 0, 0, 0, 0, 0}, tr_seg = 0, tr_t = 0, tr_rt0 = 0;   // trace build (option igemm_trace) only
     if (FFR_TRACE_ON(a.trace)) tr_rt0 = __builtin_amdgcn_s_memrealtime();
     while (u < uend) {
     const int tile_id = (int)(u / a.nkt);

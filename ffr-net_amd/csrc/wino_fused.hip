@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     }
     if (mb >= a.mbn) return;
     const int nkc = a.nkc;
-    unsigned long long st0 = 0, st1 = 0, st2 = 0, se[4] = {0, 0, 0, 0};      // FFR_WF_TRACE (diagnostics): shader-clock stamps of the phases
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, se[4] = {0, 0, 0, 0};      // trace build (option wf_trace): shader-clock stamps of the phases
     if (FFR_TRACE_ON(a.trace)) st0 = __builtin_amdgcn_s_memtime();
     // epilogue tables (their LDS is never aliased; the epilogue's first barrier publishes them)
     const int tid = threadIdx.x;

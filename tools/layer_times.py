@@ -19,4 +19,21 @@ for r in rows[s:e]:
 print('--- per step, us')
 for n, d in sorted(tot.items(), key=lambda x: -x[1]):
     print('%10.1f  %s' % (d, n[-70:]))
-print('%10.1f  total kernel time; wall %.1f' % (sum(tot.values()), (int(rows[e]['Start_Timestamp']) - int(rows[s]['Start_Timestamp'])) / 1000))
+wall = (int(rows[e]['Start_Timestamp']) - int(rows[s]['Start_Timestamp'])) / 1000
+print('%10.1f  total kernel time; wall %.1f' % (sum(tot.values()), wall))
+# time in which NO kernel runs (launch gaps; kernels of the two streams may overlap: union of the busy intervals)
+iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows[s:e])
+busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+gaps = []
+for a, b in iv[1:]:
+    if a > cur_e:
+        busy += cur_e - cur_s
+        gaps.append((a - cur_e) / 1000)
+        cur_s, cur_e = a, b
+    else:
+        cur_e = max(cur_e, b)
+busy += cur_e - cur_s
+gaps.sort()
+print('%10.1f  us with at least one kernel running; %.1f us idle in %d gaps (median %.2f, p90 %.2f, max %.1f us)'
+      % (busy / 1000, wall - busy / 1000, len(gaps), gaps[len(gaps) // 2] if gaps else 0, gaps[int(len(gaps) * 0.9)] if gaps else 0,
+         gaps[-1] if gaps else 0))
