@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_combine(const float* __restrict__ res, 
         const int c4 = (int)(idx - m * cq) * 4;
         const int n = (int)(m / HoWo);
         const f32x4 r = *reinterpret_cast<const f32x4*>(res + m * C + c4);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + (size_t)n * C + c4);
+        const f32x4 s = scale ? *reinterpret_cast<const f32x4*>(scale + (size_t)n * C + c4) : (f32x4){1.f, 1.f, 1.f, 1.f};
         f32x4 sh;
         if (sc) {
             sh = *reinterpret_cast<const f32x4*>(sc + m * C + c4);

@@ -157,17 +157,22 @@ void free_list(std::vector<void*>& v) {
     v.clear();
 }
 
-const int STAGES[4][3] = {{64, 64, 3}, {64, 128, 4}, {128, 256, 14}, {256, 512, 3}};
+// get_blocks(num_layers), pretrain/model_ir_se50.py:84-105: units per stage for 50 / 100 / 152 layers
+const int STAGE_CH[4][2] = {{64, 64}, {64, 128}, {128, 256}, {256, 512}};
+const int UNITS[3][4] = {{3, 4, 14, 3}, {3, 13, 30, 3}, {3, 8, 36, 3}};
 
-void block_table(int cin[24], int depth[24], int stride[24]) {
-    int k = 0;
-    for (auto& st : STAGES)
-        for (int u = 0; u < st[2]; ++u) {
-            cin[k] = u == 0 ? st[0] : st[1];
-            depth[k] = st[1];
-            stride[k] = u == 0 ? 2 : 1;
-            ++k;
-        }
+bool block_table(int n_blocks, std::vector<int>& cin, std::vector<int>& depth, std::vector<int>& stride) {
+    for (auto& units : UNITS) {
+        if (units[0] + units[1] + units[2] + units[3] != n_blocks) continue;
+        for (int s = 0; s < 4; ++s)
+            for (int u = 0; u < units[s]; ++u) {
+                cin.push_back(u == 0 ? STAGE_CH[s][0] : STAGE_CH[s][1]);
+                depth.push_back(STAGE_CH[s][1]);
+                stride.push_back(u == 0 ? 2 : 1);
+            }
+        return true;
+    }
+    return false;
 }
 
 // ---- convolution dispatch --------------------------------------------------------------
@@ -672,16 +677,18 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         const int tiles = ((ho + 3) / 4) * ((wo + 3) / 4);
         const bool se_fuse = h->opt.se_fuse != 0;
         const int se_maxtiles = h->opt.se_maxtiles;
-        if (se_fuse && b.stride == 1 && tiles <= se_maxtiles && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
+        if (b.fc1 && se_fuse && b.stride == 1 && tiles <= se_maxtiles && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
         if (chained) c2.wino_stage = 2;
         RC(run_conv(h, b.c2, c2, st));
-        {
+        const float* se_scale = nullptr;          // bottleneck_IR (mode 'ir'): no SEModule, the combine is res + shortcut
+        if (b.fc1) {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_SE, e + 4.0 * N * b.depth * (b.depth / 16), 4.0 * e);
             if (pooled) HIPCK(h, launch_se_fc(w.se_part, N, tiles, ho * wo, b.depth, b.fc1, b.fc2, w.scale, st));
             else HIPCK(h, launch_se(w.res, N, ho * wo, b.depth, b.fc1, b.fc2, w.scale, w.se_part, st));
+            se_scale = w.scale;
         }
         const float* scp = nullptr;
         if (b.has_sc) {
@@ -699,12 +706,12 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             wino_accepts_ready_v(h, h->blocks[i + 1].c1, N, ho, wo, b.depth, w.wino_cap)) {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 4.0 * (3.0 * e + 36.0 * N * ((ho + 3) / 4) * ((wo + 3) / 4) * b.depth));
-            HIPCK(h, launch_combine_in_c(w.res, w.scale, scp ? scp : cur, nxt, w.winoV, N, ho, wo, b.depth, st));
+            HIPCK(h, launch_combine_in_c(w.res, se_scale, scp ? scp : cur, nxt, w.winoV, N, ho, wo, b.depth, st));
             v_ready = true;
         } else {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 12.0 * e);
-            HIPCK(h, launch_combine(w.res, w.scale, scp, cur, nxt, N, ho, wo, b.depth, b.stride, st));
+            HIPCK(h, launch_combine(w.res, se_scale, scp, cur, nxt, N, ho, wo, b.depth, b.stride, st));
         }
         float* t = cur; cur = nxt; nxt = t;
         ch = ho; cw = wo; cc = b.depth;
@@ -717,7 +724,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
                 hipStream_t st, const U8In* u8, const float* x2, int n_split) {
     float* t; int oh, ow, oc;
-    RC(run_trunk(h, w, x, N, H, W, 24, st, &t, &oh, &ow, &oc, u8, x2, n_split));
+    RC(run_trunk(h, w, x, N, H, W, (int)h->blocks.size(), st, &t, &oh, &ow, &oc, u8, x2, n_split));
     const int P = oh * ow;
     if (featmap_nhwc) {
         Scope s(h, st, FFR_KC_HEAD, 2.0 * N * P * 512, 8.0 * N * P * 512);
@@ -911,11 +918,17 @@ int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
         RC(upload(h, own, b, &h->stem_b));
         RC(upload(h, own, s, &h->stem_s));
     }
-    int cin[24], depth[24], stride[24];
-    block_table(cin, depth, stride);
-    for (int i = 0; i < 24; ++i) {
+    // Backbone(num_layers, ., mode): the number of bottlenecks tells num_layers (24 / 49 / 50 = 50 / 100 / 152 layers,
+    // model_ir_se50.py:84-105), the presence of res_layer.5 the mode ('ir_se' with the SEModule, 'ir' without, :113-116)
+    int n_blocks = 0;
+    while (sd.m.count("body." + std::to_string(n_blocks) + ".res_layer.1.weight")) ++n_blocks;
+    std::vector<int> cin, depth, stride;
+    if (!block_table(n_blocks, cin, depth, stride))
+        return fail(h, FFR_ERR_KEY, "the state_dict holds %d bottlenecks; Backbone has 24, 49 or 50 (num_layers 50, 100, 152)", n_blocks);
+    const bool has_se = sd.m.count("body.0.res_layer.5.fc1.weight") != 0;
+    h->blocks.assign(n_blocks, Block());
+    for (int i = 0; i < n_blocks; ++i) {
         Block& b = h->blocks[i];
-        b = Block();
         b.cin = cin[i]; b.depth = depth[i]; b.stride = stride[i];
         const std::string p = "body." + std::to_string(i);
         BNFold bn1, bn2;
@@ -923,13 +936,15 @@ int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
         const float* W1 = sd.get(p + ".res_layer.1.weight", {b.depth, b.cin, 3, 3});
         const float* sl = sd.get(p + ".res_layer.2.weight", {b.depth});
         const float* W2 = sd.get(p + ".res_layer.3.weight", {b.depth, b.depth, 3, 3});
-        const float* f1 = sd.get(p + ".res_layer.5.fc1.weight", {b.depth / 16, b.depth, 1, 1});
-        const float* f2 = sd.get(p + ".res_layer.5.fc2.weight", {b.depth, b.depth / 16, 1, 1});
-        if (!W1 || !sl || !W2 || !f1 || !f2) return sd.rc;
+        const float* f1 = has_se ? sd.get(p + ".res_layer.5.fc1.weight", {b.depth / 16, b.depth, 1, 1}) : nullptr;
+        const float* f2 = has_se ? sd.get(p + ".res_layer.5.fc2.weight", {b.depth, b.depth / 16, 1, 1}) : nullptr;
+        if (!W1 || !sl || !W2 || (has_se && (!f1 || !f2))) return sd.rc;
         RC(pack_conv(h, own, W1, b.depth, b.cin, 3, 3, &bn1, nullptr, sl, 1, 1, 0, &b.c1));
         RC(pack_conv(h, own, W2, b.depth, b.depth, 3, 3, nullptr, &bn2, nullptr, b.stride, 1, 0, &b.c2));
-        RC(upload(h, own, std::vector<float>(f1, f1 + (size_t)b.depth / 16 * b.depth), &b.fc1));
-        RC(upload(h, own, std::vector<float>(f2, f2 + (size_t)b.depth / 16 * b.depth), &b.fc2));
+        if (has_se) {
+            RC(upload(h, own, std::vector<float>(f1, f1 + (size_t)b.depth / 16 * b.depth), &b.fc1));
+            RC(upload(h, own, std::vector<float>(f2, f2 + (size_t)b.depth / 16 * b.depth), &b.fc2));
+        }
         b.has_sc = b.cin != b.depth;
         if (b.has_sc) {
             BNFold bns;
@@ -1327,7 +1342,7 @@ int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, 
 
 int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, int n_blocks, float* out, void* stream) {
     FFR_DEVICE_SCOPE(h); RC(check_fwd(h, true, false, N));
-    if (!x || !out || n_blocks < 0 || n_blocks > 24) return fail(h, FFR_ERR_ARG, "ffr_encoder_trunk_nhwc: bad arguments");
+    if (!x || !out || n_blocks < 0 || n_blocks > (int)h->blocks.size()) return fail(h, FFR_ERR_ARG, "ffr_encoder_trunk_nhwc: bad arguments");
     if (H < 32 || W < 32 || (H & 15) || (W & 15)) return fail(h, FFR_ERR_ARG, "H and W must be multiples of 16, >= 32");
     hipStream_t st = (hipStream_t)stream;
     Work w;

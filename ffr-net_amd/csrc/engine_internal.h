@@ -83,7 +83,7 @@ struct ffr_handle {
     std::vector<void*> enc_allocs, rec_allocs;
     bool enc_loaded = false, rec_loaded = false;
     float *stem_w = nullptr, *stem_b = nullptr, *stem_s = nullptr;
-    ffr_eng::Block blocks[24];
+    std::vector<ffr_eng::Block> blocks;      // 24 / 49 / 50 bottlenecks: Backbone(50 | 100 | 152), with or without SE
     float *bn_s = nullptr, *bn_t = nullptr;
     ffr_eng::ConvW fc;
     ffr_eng::ConvW sp[9], fm[3], mg[3];

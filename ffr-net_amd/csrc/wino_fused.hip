@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_combine_in_c(const float* __restrict__ 
         for (int p = tid >> 3; p < npx; p += 32) {
             const int il = p / HW;
             const size_t off = ((size_t)n_first * HW + p) * C + cb + q4;
-            const f32x4 sv = *reinterpret_cast<const f32x4*>(scale + (size_t)(n_first + il) * C + cb + q4);
+            const f32x4 sv = scale ? *reinterpret_cast<const f32x4*>(scale + (size_t)(n_first + il) * C + cb + q4) : (f32x4){1.f, 1.f, 1.f, 1.f};
             const f32x4 x = *reinterpret_cast<const f32x4*>(res + off) * sv + *reinterpret_cast<const f32x4*>(sh + off);
             *reinterpret_cast<f32x4*>(out + off) = x;
             *reinterpret_cast<f32x4*>(s_x + p * 32 + q4) = x;

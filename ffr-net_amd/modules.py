@@ -14,7 +14,7 @@ rebuilt whenever a parameter or buffer changes: every forward compares the ident
 version counter of each tensor in the tree with what was packed (load_state_dict, .to(),
 in-place edits, a Parameter replaced on a sub-module).
 
-Backbone is eval-only (the reference never trains it, models/trainer.py:62-63); RecNet runs
+Backbone covers every configuration the reference defines (num_layers 50 / 100 / 152, mode 'ir' / 'ir_se'); it is eval-only (the reference never trains it, models/trainer.py:62-63); RecNet runs
 natively in eval() (label=None -> 2-tuple) and in train() mode (label given -> the 7-tuple,
 differentiable through the native backward).  There is no CPU or stock-torch fallback anywhere
 in this package.
@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from .native import Engine
-from .synth import irse50_blocks
+from .synth import ir_blocks
 
 
 def l2_norm(input, axis=1):
@@ -64,6 +64,24 @@ class bottleneck_IR_SE(_Holder):
             nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
             nn.BatchNorm2d(depth),
             SEModule(depth, 16))
+
+
+class bottleneck_IR(_Holder):
+    """pretrain/model_ir_se50.py:38-54: bottleneck_IR_SE without the SEModule (Backbone mode 'ir')."""
+
+    def __init__(self, in_channel, depth, stride):
+        super().__init__()
+        if in_channel == depth:
+            self.shortcut_layer = nn.MaxPool2d(1, stride)
+        else:
+            self.shortcut_layer = nn.Sequential(
+                nn.Conv2d(in_channel, depth, (1, 1), stride, bias=False), nn.BatchNorm2d(depth))
+        self.res_layer = nn.Sequential(
+            nn.BatchNorm2d(in_channel),
+            nn.Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False),
+            nn.PReLU(depth),
+            nn.Conv2d(depth, depth, (3, 3), stride, 1, bias=False),
+            nn.BatchNorm2d(depth))
 
 
 class _NativeModule(nn.Module):
@@ -138,15 +156,14 @@ class Backbone(_NativeModule):
         super().__init__()
         assert num_layers in [50, 100, 152], 'num_layers should be 50,100, or 152'
         assert mode in ['ir', 'ir_se'], 'mode should be ir or ir_se'
-        if num_layers != 50 or mode != 'ir_se':
-            raise NotImplementedError('ffrnet_amd: only Backbone(50, *, "ir_se") (IR-SE50, the one '
-                                      'the reference instantiates, model_ir_se50.py:150) is native')
+        self.num_layers, self.mode = num_layers, mode
+        unit = bottleneck_IR if mode == 'ir' else bottleneck_IR_SE        # model_ir_se50.py:113-116
         self.input_layer = nn.Sequential(nn.Conv2d(3, 64, (3, 3), 1, 1, bias=False),
                                          nn.BatchNorm2d(64), nn.PReLU(64))
         self.output_layer = nn.Sequential(nn.BatchNorm2d(512), nn.Dropout(drop_ratio), Flatten(),
                                           nn.Linear(512 * 7 * 7, 512), nn.BatchNorm1d(512))
         self.bn = nn.BatchNorm2d(512)
-        self.body = nn.Sequential(*[bottleneck_IR_SE(c, d, s) for c, d, s in irse50_blocks()])
+        self.body = nn.Sequential(*[unit(c, d, s) for c, d, s in ir_blocks(num_layers)])
 
     def forward(self, x):
         """-> (featmap[N,512,7,7], l2_norm(feat)[N,512]); model_ir_se50.py:136-141."""

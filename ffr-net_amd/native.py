@@ -200,6 +200,10 @@ class Engine(object):
         arr, n, keep = self._descs(state_dict)
         self._ck(self.lib.ffr_load_encoder(self._h, arr, n))
         self.has_encoder = True
+        nblk = 0
+        while 'body.%d.res_layer.1.weight' % nblk in state_dict:
+            nblk += 1
+        self.num_layers = {24: 50, 49: 100, 50: 152}[nblk]
 
     def load_recnet(self, state_dict):
         arr, n, keep = self._descs(state_dict)
@@ -573,8 +577,8 @@ class Engine(object):
         x = x.contiguous()
         n, _, h, w = x.shape
         chans, div = 64, 1
-        from .synth import irse50_blocks
-        for cin, depth, stride in irse50_blocks()[:n_blocks]:
+        from .synth import ir_blocks
+        for cin, depth, stride in ir_blocks(getattr(self, 'num_layers', 50))[:n_blocks]:
             chans, div = depth, div * stride
         out = torch.empty((n, h // div, w // div, chans), device=x.device, dtype=torch.float32)
         with torch.cuda.device(self.device):

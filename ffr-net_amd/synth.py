@@ -15,17 +15,22 @@ import zlib
 import numpy as np
 import torch
 
-# Block table of IR-SE50: (in_channel, depth, stride) for the 24 bottlenecks.
-# Restates get_blocks(50) / get_block of pretrain/model_ir_se50.py:81-91.
+# Block tables: (in_channel, depth, stride) of every bottleneck.
+# Restates get_blocks(num_layers) / get_block of pretrain/model_ir_se50.py:78-105.
+IR_UNITS = {50: (3, 4, 14, 3), 100: (3, 13, 30, 3), 152: (3, 8, 36, 3)}
 IRSE50_STAGES = ((64, 64, 3), (64, 128, 4), (128, 256, 14), (256, 512, 3))
 
 
-def irse50_blocks():
+def ir_blocks(num_layers=50):
     blocks = []
-    for cin, depth, units in IRSE50_STAGES:
+    for (cin, depth, _), units in zip(IRSE50_STAGES, IR_UNITS[num_layers]):
         blocks.append((cin, depth, 2))
         blocks.extend((depth, depth, 1) for _ in range(units - 1))
     return blocks
+
+
+def irse50_blocks():
+    return ir_blocks(50)
 
 
 def _gen(key, seed):

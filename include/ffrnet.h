@@ -63,7 +63,9 @@ const char* ffr_version(void);
  * Eval-mode BatchNorm is folded, weights are re-packed [Cout][R][S][Cin] for the
  * NHWC implicit-GEMM kernels and uploaded; the caller keeps ownership of `t`.
  * Encoder = IR-SE50 (Backbone(50, drop, 'ir_se')): 347 fp32 entries (402 with the
- * integer num_batches_tracked counters, which are not passed).
+ * integer num_batches_tracked counters, which are not passed).  Backbone(100 | 152, drop, 'ir' | 'ir_se')
+ * (pretrain/model_ir_se50.py:84-116) load as well: the number of body.N entries (24 / 49 / 50 bottlenecks) tells
+ * num_layers, the presence of res_layer.5 the mode; any other count returns FFR_ERR_KEY.
  * RecNet  = RecNet(512, 7, 'bn', 'prelu'): 106 fp32 entries (121 in all); "classifier.weight"
  * (training-only head, models/recnet.py:396) is ignored if present.               */
 int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n);

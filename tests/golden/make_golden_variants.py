@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/g10_backbone_variants.{json,npz} by running THE REFERENCE ITSELF on CPU: the Backbone
+configurations the reference defines but never instantiates (pretrain/model_ir_se50.py:84-116: num_layers 100 / 152,
+mode 'ir' = bottleneck_IR without the SEModule).
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden_variants.py
+Stored: the state_dict key -> shape lists (the drop-in contract) and, for 2 seeded images, f, the trunk-output statistics and
+strided samples of featmap.  Weights and images are regenerated from ffr-net_amd/synth.py, never stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+from ffrnet_amd import synth  # noqa: E402
+
+VARIANTS = [(50, 'ir'), (100, 'ir'), (100, 'ir_se'), (152, 'ir_se')]
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    m_enc, _, _ = mg.import_reference()
+    x = synth.synth_images(2, 112, 112, seed=131)
+    keys, out = {}, {}
+    for num_layers, mode in VARIANTS:
+        tag = '%d_%s' % (num_layers, mode)
+        enc = m_enc.Backbone(num_layers=num_layers, drop_ratio=0.6, mode=mode)
+        spec = {k: list(v.shape) for k, v in enc.state_dict().items()}
+        keys[tag] = spec
+        enc.load_state_dict(synth.synth_state_dict(spec, seed=0))
+        enc.eval()
+        with torch.no_grad():
+            featmap, f = enc(x)
+        out[tag + '.f'] = f.numpy()
+        out[tag + '.featmap_samples'] = mg.strided(featmap, 512).numpy()
+        out[tag + '.featmap_absmax'] = np.float64(featmap.abs().max().item())
+        out[tag + '.featmap_mean'] = np.float64(featmap.double().mean().item())
+        out[tag + '.featmap_std'] = np.float64(featmap.double().std().item())
+        print(tag, len(spec), 'entries; featmap absmax %.3f' % featmap.abs().max().item())
+    with open(os.path.join(HERE, 'g10_backbone_variant_keys.json'), 'w') as fh:
+        json.dump(keys, fh, indent=0)
+    np.savez_compressed(os.path.join(HERE, 'g10_backbone_variants.npz'),
+                        input_checksum=np.float64(x.double().sum().item()), **out)
+
+
+if __name__ == '__main__':
+    main()

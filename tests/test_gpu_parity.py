@@ -297,6 +297,37 @@ def test_encoder_forward_and_trunk_112x96_full_size(engine, state_dicts):
         assert torch.isfinite(fm).all()
 
 
+@pytest.mark.parametrize('tag', ['50_ir', '100_ir', '100_ir_se', '152_ir_se'])
+def test_backbone_variants(golden_dir, tag):
+    """Backbone(100 | 152, ., 'ir' | 'ir_se') (pretrain/model_ir_se50.py:84-116; the reference defines them, its scripts
+    use (50, 'ir_se') only): the engine reads the configuration off the state_dict (49 / 50 bottlenecks, res_layer.5 or
+    not).  2 images against golden G10 = the reference's own outputs, then batch 40 against the batch-2 run; through
+    the drop-in shell as well."""
+    spec = json.load(open(os.path.join(golden_dir, 'g10_backbone_variant_keys.json')))[tag]
+    g = np.load(os.path.join(golden_dir, 'g10_backbone_variants.npz'))
+    sd = synth.synth_state_dict(spec, seed=0)
+    num_layers, mode = int(tag.split('_')[0]), tag.split('_', 1)[1]
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd)
+    assert eng.num_layers == num_layers
+    x = synth.synth_images(2, 112, 112, seed=131).cuda()
+    featmap, f = eng.encoder_forward(x)
+    assert rel(f, torch.from_numpy(g[tag + '.f'])) < 2e-4
+    flat = featmap.reshape(-1)
+    step = max(1, flat.numel() // 512)
+    assert (flat[::step][:512].cpu() - torch.from_numpy(g[tag + '.featmap_samples'])).abs().max().item() < \
+        2e-4 * float(g[tag + '.featmap_absmax'])
+    xb = synth.synth_images(40, 112, 112, seed=132).cuda()
+    xb[:2] = x
+    fm40, f40 = eng.encoder_forward(xb)
+    assert rel(f40[:2], f) < 2e-5 and rel(fm40[:2], featmap) < 2e-5 and torch.isfinite(fm40).all()
+    shell = ffrnet_amd.Backbone(num_layers=num_layers, drop_ratio=0.6, mode=mode)
+    shell.load_state_dict(sd)
+    fm_s, f_s = shell.cuda().eval()(x)
+    assert torch.equal(fm_s, featmap) and torch.equal(f_s, f)
+    eng.close()
+
+
 def test_se_module_isolated(engine, state_dicts):
     """SEModule (pretrain/model_ir_se50.py:18-36) on its own: block 2's squeeze-excitation scale, recovered from
     the trunk taps around it -- res * sigmoid(fc2(relu(fc1(avgpool(res))))) + shortcut -- against torch ops on the

@@ -37,8 +37,7 @@ def test_state_dict_key_contract(specs):
 
 
 def test_unsupported_constructor_arguments():
-    with pytest.raises(NotImplementedError):
-        ffrnet_amd.Backbone(100, 0.6, 'ir_se')
+    assert len(ffrnet_amd.Backbone(100, 0.6, 'ir').body) == 49 and len(ffrnet_amd.Backbone(152, 0.6, 'ir_se').body) == 50
     with pytest.raises(NotImplementedError):
         ffrnet_amd.RecNet(norm_type='in')
     with pytest.raises(AssertionError):
