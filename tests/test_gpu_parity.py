@@ -658,6 +658,25 @@ def test_rccl_one_rank_runs_the_product_collectives():
     assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
 
 
+def test_options_api(engine):
+    """ffr_set_option / ffr_get_option: the only way to switch kernels (the library reads no environment): defaults,
+    round trip, unknown names, out-of-range values, trace options rejected by the shipped (non -DFFR_TRACE) build."""
+    assert engine.get_option('wf_minblocks') == 200 and engine.get_option('wino') == 1 and engine.get_option('combine_v') == 1
+    engine.set_option('wf_minblocks', 123)
+    assert engine.get_option('wf_minblocks') == 123
+    engine.set_option('wf_minblocks', 200)
+    for bad in (lambda: engine.set_option('no_such_option', 1), lambda: engine.set_option('wino', 2),
+                lambda: engine.set_option('sk_minunits', 0), lambda: engine.get_option('nope'),
+                lambda: engine.set_option('wf_trace', 1), lambda: engine.set_option('igemm_trace', 1)):
+        with pytest.raises(RuntimeError):
+            bad()
+    assert engine.get_option('wf_trace') == 0
+    src = ''
+    for fn in os.listdir(os.path.join(ROOT, 'ffr-net_amd', 'csrc')):
+        src += open(os.path.join(ROOT, 'ffr-net_amd', 'csrc', fn)).read()
+    assert 'getenv' not in src
+
+
 @pytest.mark.gpu
 def test_experiment_knobs_keep_parity(tmp_path):
     """The A/B knobs of DESIGN.md 3.3 (ffr_set_option; tools/knob_embed.py maps FFR_OPT_<NAME> in ITS environment to

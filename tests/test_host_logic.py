@@ -63,6 +63,18 @@ def test_no_cpu_fallback():
     assert not re.search(r'^\s*(import|from)\s+\.*(oracle|ffr_oracle)', src, re.M)
 
 
+def test_library_reads_no_environment():
+    """kernel selection must not depend on environment variables -- every knob is an option of the handle
+    (ffr_set_option).  Static check of the native sources and of the built library's dynamic imports."""
+    src = ''
+    for fn in os.listdir(os.path.join(ROOT, 'ffr-net_amd', 'csrc')):
+        src += open(os.path.join(ROOT, 'ffr-net_amd', 'csrc', fn)).read()
+    assert 'getenv' not in src and 'environ[' not in src and 'secure_getenv' not in src
+    out = subprocess.run(['nm', '-D', '--undefined-only', native.lib_path()], capture_output=True, text=True)
+    if out.returncode == 0:
+        assert 'getenv' not in out.stdout
+
+
 def test_c_abi_exports_every_declared_symbol():
     """The .so loads without a GPU and exports each function include/*.h declares."""
     path = native.lib_path()
