@@ -206,6 +206,9 @@ def calculate_distance(data_loader, encoder, recnet=None, flag=0, use_flip=False
         s_old.append(fn(e[:, 2 * d:3 * d], e[:, 3 * d:]))
         labels.append(torch.as_tensor(data['label']).reshape(-1).double().cpu())
         idxs.append(torch.as_tensor(data['idx']).reshape(-1).double().cpu())
+    if not s_new:                                # empty loader: the reference returns empty arrays as well
+        z = np.zeros((0, 3))
+        return (z, z.copy(), torch.zeros(0), torch.zeros(0)) if device_scores else (z, z.copy())
     dev_new, dev_old = torch.cat(s_new), torch.cat(s_old)
     h_new = dev_new.double().cpu().numpy()      # one device->host sync at the end
     h_old = dev_old.double().cpu().numpy()
