@@ -44,7 +44,7 @@ def main():
         out[tag + '.featmap_std'] = np.float64(featmap.double().std().item())
         print(tag, len(spec), 'entries; featmap absmax %.3f' % featmap.abs().max().item())
     with open(os.path.join(HERE, 'g10_backbone_variant_keys.json'), 'w') as fh:
-        json.dump(keys, fh, indent=0)
+        json.dump(keys, fh, separators=(',', ':'))
     np.savez_compressed(os.path.join(HERE, 'g10_backbone_variants.npz'),
                         input_checksum=np.float64(x.double().sum().item()), **out)
 
