@@ -151,7 +151,7 @@ def pmc_traffic(sha, live=True):
             env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
             for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
                 env.pop(k, None)
-            subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_bench.sh')], env=env, cwd=ROOT, timeout=600,
+            subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_bench.sh')], env=env, cwd=ROOT, timeout=420,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             with open(os.path.join(ROOT, 'gpurun_out', 'pmc_bench', 'summary.json')) as f:
                 d = json.load(f)

@@ -10,7 +10,7 @@ rm -rf -- "$OUT"; mkdir -p -- "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   d=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>"$OUT/$d.err"
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>"$OUT/$d.err"
 done
 python3 - <<PY
 import csv, glob, collections, json, hashlib
