@@ -75,7 +75,7 @@ def self_launch(args):
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # a rank that dies must not leave the others waiting at the rendezvous (or in a collective) until a timeout: the
@@ -123,13 +123,30 @@ def so_sha256():
     return h.hexdigest()
 
 
-def pmc_traffic(sha, live=True):
+def under_profiler():
+    """True when this process runs under rocprofv3 / rocprof (its tool library is preloaded or its environment set)."""
+    if any(k.startswith(('ROCP_', 'ROCPROF', 'ROCPROFILER_')) for k in os.environ):
+        return True
+    return any('rocprof' in os.environ.get(k, '') for k in ('LD_PRELOAD', 'HSA_TOOLS_LIB'))
+
+
+def _pmc_fields(d, src):
+    return {'hbm_bytes_per_launch': d['dominant']['hbm_bytes_per_launch'],
+            'launches_per_step': d['dominant']['launches_per_step'],
+            'hbm_gb_per_step_all_kernels': d['gb_per_step'],
+            'mfma_busy_frac_of_kernel_time': d['dominant'].get('mfma_busy_frac_of_kernel_time'),
+            'batch': d.get('batch', 256), 'source': src}
+
+
+def pmc_traffic(sha, batch=256, live=True):
     """HBM bytes per launch of the dominant kernel and per step from rocprofv3 --pmc passes (tools/pmc_bench.sh:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane
     streams on gfx950).  PMC counters cannot be read from inside this process: the committed summary of the round
-    (profiles/r*_pmc_hbm_traffic.json) carries the sha256 of the library it was measured with and is used when that is
-    the library loaded here; for any other build the passes are run now, as child processes (about two minutes), so a
-    rebuilt library never silently loses the figure."""
+    (profiles/r*_pmc_hbm_traffic.json) carries the sha256 of the library AND the batch it was measured with and is used
+    when both match this run; otherwise the passes are run now, as child processes in their own process group (three
+    passes, bounded below the timeout used here; the whole group is killed on a timeout so that no profiler pass keeps
+    the GPU busy under the measurements that follow), with the profiler's own environment stripped.  Never nested:
+    when this process itself runs under rocprofv3 the figure is reported as absent instead."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), reverse=True):
         try:
@@ -137,37 +154,49 @@ def pmc_traffic(sha, live=True):
                 d = json.load(f)
         except Exception:
             continue
-        if d.get('so_sha256') == sha and 'dominant' in d:
+        if d.get('so_sha256') == sha and 'dominant' in d and d.get('batch', 256) == batch:
             rel = os.path.relpath(path, ROOT)
-            return {'hbm_bytes_per_launch': d['dominant']['hbm_bytes_per_launch'],
-                    'launches_per_step': d['dominant']['launches_per_step'],
-                    'hbm_gb_per_step_all_kernels': d['gb_per_step'],
-                    'mfma_busy_frac_of_kernel_time': d['dominant'].get('mfma_busy_frac_of_kernel_time'),
-                    'source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same build: sha256 %s...)' % (rel, sha[:12])}
+            return _pmc_fields(d, '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same build: sha256 %s..., batch %d)'
+                               % (rel, sha[:12], batch))
     import shutil
-    if live and shutil.which('rocprofv3') and os.environ.get('FFR_BENCH_LIVE_PMC', '1') != '0':
+    import signal
+    why = 'live passes disabled'
+    if live and shutil.which('rocprofv3') and os.environ.get('FFR_BENCH_LIVE_PMC', '1') != '0' and not under_profiler():
+        t0 = time.perf_counter()
+        env = {k: v for k, v in os.environ.items()
+               if not k.startswith(('ROCP_', 'ROCPROF', 'ROCPROFILER_')) and k not in ('LD_PRELOAD', 'HSA_TOOLS_LIB',
+                                                                                        'RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+        env.update(GRAFT_REPO_ROOT=ROOT, FFR_PMC_BATCH=str(batch), FFR_PMC_PASS_TIMEOUT='110', FFR_BENCH_LIVE_PMC='0')
+        proc = None
         try:
-            t0 = time.perf_counter()
-            env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
-            for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
-                env.pop(k, None)
-            subprocess.run(['bash', os.path.join(ROOT, 'tools', 'pmc_bench.sh')], env=env, cwd=ROOT, timeout=420,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            proc = subprocess.Popen(['bash', os.path.join(ROOT, 'tools', 'pmc_bench.sh')], env=env, cwd=ROOT,
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            rc = proc.wait(timeout=380)                 # 3 passes x 110 s + the summary < 380 s
+            if rc != 0:
+                raise RuntimeError('tools/pmc_bench.sh exited with %d' % rc)
             with open(os.path.join(ROOT, 'gpurun_out', 'pmc_bench', 'summary.json')) as f:
                 d = json.load(f)
-            if d.get('so_sha256') == sha and 'dominant' in d:
-                return {'hbm_bytes_per_launch': d['dominant']['hbm_bytes_per_launch'],
-                        'launches_per_step': d['dominant']['launches_per_step'],
-                        'hbm_gb_per_step_all_kernels': d['gb_per_step'],
-                        'mfma_busy_frac_of_kernel_time': d['dominant'].get('mfma_busy_frac_of_kernel_time'),
-                        'source': 'measured in this run: tools/pmc_bench.sh as child processes (rocprofv3 --pmc, %.0f s); no '
-                                  'committed summary matches this build (sha256 %s...)' % (time.perf_counter() - t0, sha[:12])}
+            if d.get('so_sha256') == sha and 'dominant' in d and d.get('batch', 256) == batch:
+                return _pmc_fields(d, 'measured in this run: tools/pmc_bench.sh as child processes (rocprofv3 --pmc, %.0f s); '
+                                      'no committed summary matches this build (sha256 %s...) and batch %d'
+                                   % (time.perf_counter() - t0, sha[:12], batch))
+            why = 'the live passes measured another build or batch'
         except Exception as e:          # no profiler, no permission, timeout: say so instead of inventing a number
-            return {'hbm_bytes_per_launch': None, 'note': 'no committed PMC summary matches this build (sha256 %s...) and the '
-                    'live rocprofv3 --pmc passes failed: %s' % (sha[:12], str(e)[:200])}
+            if proc is not None and proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)         # bash, timeout, rocprofv3 and its python child
+                except Exception:
+                    pass
+                try:
+                    proc.wait(timeout=30)
+                except Exception:
+                    pass
+            why = 'the live rocprofv3 --pmc passes failed: %s' % str(e)[:200]
+    elif under_profiler():
+        why = 'this run is itself under a profiler (no nested rocprofv3)'
     return {'hbm_bytes_per_launch': None,
-            'note': 'no profiles/r*_pmc_hbm_traffic.json was measured with this build of libffrnet_hip.so (sha256 %s...): '
-                    're-run tools/pmc_bench.sh' % sha[:12]}
+            'note': 'no profiles/r*_pmc_hbm_traffic.json was measured with this build of libffrnet_hip.so (sha256 %s...) at '
+                    'batch %d; %s: re-run tools/pmc_bench.sh' % (sha[:12], batch, why)}
 
 
 def host_cores():
@@ -328,15 +357,19 @@ def train_workload(args, world, rank, local, dist):
         dt = t.item()
     assert all(torch.isfinite(l) for l in items)
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # executed FLOPs of the MFMA kernels of one iteration over their hipEvent time on the launch stream: k_wino_fused
         # (encoder + RecNet forward + data gradients), k_igemm / k_gemm_stream (direct and batched-GEMM convolutions, linears)
-        # and k_wgrad (weight gradients as TN GEMMs)
-        eng.profile_enable(True)
+        # and k_wgrad (weight gradients as TN GEMMs).  tr.step() contains the gradient all-reduce, a COLLECTIVE: every rank
+        # runs the profiled iterations (a rank that skipped them would leave rank 0 waiting in RCCL forever); only rank 0
+        # instruments its launches and reports.
+        if rank == 0:
+            eng.profile_enable(True)
         nprof = 2
         for _ in range(nprof):
             tr.step(non, ocl, label)
-        torch.cuda.synchronize()
+        fence()
+    if rank == 0 and not args.no_roofline:
         st = eng.profile_read()
         eng.profile_enable(False)
         cls = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches_per_step': v['launches'] // nprof,
@@ -372,6 +405,12 @@ def train_workload(args, world, rank, local, dist):
 
 def main():
     args = parse_args()
+    # Cross-process GPU memory sharing (RCCL's intra-node transport, torch's CUDA-tensor IPC) needs dmabuf IPC handles on
+    # this image's host driver: with the legacy mode RCCL fails in hipIpcGetMemHandle ("invalid argument").  The image
+    # exports HSA_ENABLE_IPC_MODE_LEGACY=0 already; a DEFAULT only (a caller's own setting wins), set at the one place
+    # every launch mode passes through -- self-launched children inherit it, torch.distributed.run ranks and the
+    # single-rank run set it themselves here, before anything initialises the GPU runtime.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
@@ -524,7 +563,7 @@ def main():
                           'convolution in one launch)',
                 'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                'traffic': pmc_traffic(sha, live=(world == 1)),   # child profiler passes only when no other rank waits on this one
+                'traffic': pmc_traffic(sha, batch=B, live=(world == 1)),   # child profiler passes only when no other rank waits on this one
                 'note': 'achieved = FLOPs the matrix cores EXECUTED in k_wino_fused (2*36*tiles*cin*cout, padding '
                         'included) / its hipEvent time; the algorithmic direct-convolution FLOPs of those layers are '
                         '4x (3.06x on 7x7 maps) larger: effective_tflops_algorithmic',

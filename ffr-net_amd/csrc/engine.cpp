@@ -1217,6 +1217,11 @@ int ffr_set_option(ffr_handle* h, const char* name, long long value) {
         FFR_DEVICE_SCOPE(h);
         hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; ++h->generation;
     }
+    // every knob changes which kernels a forward launches or which scratch buffers they use: a hipGraph captured
+    // before the change replays the OLD sequence, so a changed value invalidates captures (GraphedEmbed re-captures
+    // when ffr_generation moves)
+    const long long old = e->i ? (long long)(h->opt.*(e->i)) : h->opt.*(e->l);
+    if (old != value) ++h->generation;
     if (e->i) h->opt.*(e->i) = (int)value; else h->opt.*(e->l) = value;
     return FFR_OK;
 }

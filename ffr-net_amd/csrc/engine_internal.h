@@ -49,7 +49,7 @@ struct Options {
     int wino_fused = 1;           // 0: Winograd convolutions run as transform kernels around the batched GEMM
     int wf_phased_maxk = 128;     // largest padded cin for which k_wino_fused transforms its own input
     long long wf_minblocks = 200; // fewest block tiles for which the fused kernel is used
-    int wf_halfblocks = 1;        // 1: launches below wf_minblocks use the 16-tile block shape when that fills the chip
+    int wf_halfblocks = 1;        // 1: launches below wf_minblocks use the 32-tile x 32-channel block shape (NT = 1) when that fills the chip
     int se_maxtiles = 256;        // most 4x4 tiles per image for which the SE squeeze comes from the fused kernel's tile sums
     int wf_tailsplit = 1;         // 1: images that do not fill whole rounds of block tiles run on the second stream
     int wf_mapv = 1;              // block -> tile map of k_wino_fused (1: channel groups of a tile group share an XCD)

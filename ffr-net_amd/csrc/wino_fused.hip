@@ -464,6 +464,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         unsigned long long tp0 = 0;
         if (FFR_TRACE_ON(a.trace)) tp0 = __builtin_amdgcn_s_memtime();
         const unsigned soff = (unsigned)(ph * 32) * 4u;                   // scalar: the phase's first channel
+        // channel offset of the prefetch under the last K chunk: the next phase's -- behind the LAST phase the current
+        // one again (a raw buffer's soffset is outside the hardware range check, so `soff + 128` there would read up to
+        // 128 B past the end of x; the loads stay unconditional so that `pre` is dead between the phases)
+        const unsigned soff_next = ph + 1 < nph ? soff + 128u : soff;
         {
         f32x4 d[6][6];
 #pragma unroll
@@ -521,9 +525,9 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                             else if (c < 3) loadu(j - 1, part, up + 36 * 512);             // xi j-1 of the next chunk
                         }
                         // last chunk: two patch values of the next phase per step take the place of the weight loads
-                        if (c == 3 && j >= 1 && 2 * (j - 1) < NPRE) {      // (also behind the last phase: harmless, keeps `pre` dead in between)
-                            pre[2 * (j - 1)] = load_px(2 * (j - 1), soff + 128u);
-                            pre[2 * (j - 1) + 1] = load_px(2 * (j - 1) + 1, soff + 128u);
+                        if (c == 3 && j >= 1 && 2 * (j - 1) < NPRE) {
+                            pre[2 * (j - 1)] = load_px(2 * (j - 1), soff_next);
+                            pre[2 * (j - 1) + 1] = load_px(2 * (j - 1) + 1, soff_next);
                         }
                     }
                     if (g == 2 * NT && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);

@@ -129,14 +129,17 @@ class pair_embed(object):
         self.encoder, self.recnet = encoder, recnet
         self.native = isinstance(encoder, Backbone) and isinstance(recnet, RecNet)
         self.engine = None
-        self._rsig = None
 
     def _bind(self, device):
         eng = self.encoder._engine(device)              # (re)loads the encoder weights when they changed
         rsig, keep = self.recnet._signature(device)
-        if self.engine is not eng or self._rsig != rsig:
+        # what the HANDLE holds decides, not what this object loaded last: another pair_embed over the same Backbone
+        # shell, or a direct eng.load_recnet, may have replaced the RecNet weights in between (load_recnet clears the
+        # signature)
+        if eng._recnet_sig != rsig:
             eng.load_recnet(self.recnet.state_dict())
-            self.engine, self._rsig, self._keep = eng, rsig, keep
+            eng._recnet_sig, eng._recnet_keep = rsig, keep    # `keep`: the tensors stay alive, so their ids stay unique
+        self.engine = eng
         return eng
 
     def bind(self, device):
@@ -162,14 +165,130 @@ def _embed_of(encoder, recnet=None):
     return pair_embed(encoder, recnet)
 
 
+def target_device(embed_fn):
+    """The ROCm device an embed function computes on: the Engine's own device (never merely the CURRENT device: a
+    rank that forgot torch.cuda.set_device would otherwise feed cuda:0 to an Engine on cuda:r), for the two shells
+    the device their parameters live on, else the current device like the reference's `.cuda()` (lfw_eval.py:236-238).
+    None for foreign embed functions (they get the tensors as the loader made them)."""
+    eng = engine_of(embed_fn)
+    if eng is not None:
+        return eng.device
+    if getattr(embed_fn, 'native', False):
+        for p in embed_fn.encoder.parameters():
+            if p.is_cuda:
+                return p.device
+            break
+        return torch.device('cuda', torch.cuda.current_device())
+    return None
+
+
+class ShardFeeder(object):
+    """The input side of calculate_distance (replaces lfw_eval.py:236-238's three `.cuda()` calls).
+
+    For every pair batch of the loader: take THIS rank's contiguous shard `[lo:hi]` of img1 and img2 ON THE HOST, put
+    the two slices behind each other in a pinned staging buffer and copy that one block to `device` on a side stream
+    (non-blocking), one batch ahead of the consumer -- the copy of batch k+1 runs under the kernels of batch k, and a
+    rank moves only its own 2*(hi-lo) images instead of the whole pair batch (8 x less host traffic at 8 GPUs).
+    Tensors that already live on the device are sliced there (and must be on `device`).  `device=None`: no copies at
+    all (foreign embed functions, CPU tests).  Yields (data, both[2m,3,H,W], m, n).
+
+    `stats`: batches, shard_bytes (bytes of image data handed to the embed function), h2d_bytes (bytes this rank
+    copied host -> device), full_batch_bytes (what copying whole pair batches would have moved)."""
+
+    def __init__(self, data_loader, rank=0, world=1, device=None, prefetch=True):
+        self.loader, self.rank, self.world, self.device = data_loader, rank, world, device
+        self.prefetch = prefetch and device is not None
+        self.stats = dict(batches=0, shard_bytes=0, h2d_bytes=0, full_batch_bytes=0)
+        self._stage = [None, None]       # pinned host buffers
+        self._free = [None, None]        # event after which a staging buffer may be overwritten
+        self._side = None
+
+    def _produce(self, k, data):
+        """Slice, stage and start the copy of one batch; -> (data, both, m, n, ready_event | None)."""
+        img1, img2 = data['img1'], data['img2']
+        n = img1.size(0)
+        lo, hi = shard_bounds(n, self.rank, self.world)
+        m = hi - lo
+        st = self.stats
+        st['batches'] += 1
+        st['full_batch_bytes'] += (img1.numel() + img2.numel()) * img1.element_size()
+        a, b = img1[lo:hi], img2[lo:hi]                   # the shard is cut BEFORE anything is copied anywhere
+        st['shard_bytes'] += (a.numel() + b.numel()) * a.element_size()
+        if m == 0:
+            return data, None, 0, n, None
+        dev = self.device
+        if dev is None:
+            return data, torch.cat((a, b), 0), m, n, None
+        if a.is_cuda or b.is_cuda:
+            for t, nm in ((a, 'img1'), (b, 'img2')):
+                if not t.is_cuda or t.device.index != dev.index:
+                    raise RuntimeError('ffrnet_amd.lfw: %s is on %s but the embed function computes on %s'
+                                       % (nm, t.device, dev))
+            return data, torch.cat((a, b), 0), m, n, None
+        # host tensors: one pinned block [2m,...], one asynchronous copy on the side stream
+        slot = k & 1
+        shape = (2 * m,) + tuple(a.shape[1:])
+        need = 2 * m * a[0].numel()
+        buf = self._stage[slot]
+        if buf is None or buf.numel() < need or buf.dtype != a.dtype:
+            buf = torch.empty(need, dtype=a.dtype, pin_memory=True)
+            self._stage[slot] = buf
+        elif self._free[slot] is not None:
+            self._free[slot].synchronize()                # the copy that last read this buffer (two batches ago) is done
+        host = buf[:need].view(shape)
+        host[:m].copy_(a)
+        host[m:].copy_(b)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._side):
+            both = host.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._free[slot] = ev
+        st['h2d_bytes'] += need * a.element_size()
+        return data, both, m, n, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        k = 0
+        try:
+            cur = self._produce(k, next(it))
+        except StopIteration:
+            return
+        while cur is not None:
+            nxt = None
+            if self.prefetch:                             # start batch k+1's copy before batch k is consumed
+                try:
+                    nxt = self._produce(k + 1, next(it))
+                except StopIteration:
+                    nxt = False
+            data, both, m, n, ev = cur
+            if ev is not None:
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ev)
+                both.record_stream(main)                  # allocated on the side stream, consumed on this one
+            yield data, both, m, n
+            if nxt is None:
+                try:
+                    nxt = self._produce(k + 1, next(it))
+                except StopIteration:
+                    nxt = False
+            cur = nxt or None
+            k += 1
+
+
+last_feed_stats = None      # ShardFeeder.stats of the most recent calculate_distance call in this process
+
+
 def calculate_distance(data_loader, encoder, recnet=None, flag=0, use_flip=False, use_gpu=True, group=None,
                        score_fn=None, device_scores=False):
     """lfw_eval.calculate_distance(data_loader, encoder, recnet, flag, use_flip, use_gpu), lfw/lfw_eval.py:226-252.
 
     `encoder, recnet`: the two modules (the drop-in shells run natively, fused), or ONE embed function
     `embed_fn(img[N,3,112,112]) -> (f_new[N,512], f[N,512])` in `encoder`'s place (Engine.embed, GraphedEmbed)
-    with recnet=None.  data_loader yields dicts with img1, img2, label, idx (data/dataset.py:84-88); `use_gpu`
-    moves the images to the current ROCm device like the reference's `.cuda()` (:236-238).
+    with recnet=None.  data_loader yields dicts with img1, img2, label, idx (data/dataset.py:84-88); with `use_gpu`
+    host images go to the device the embed function computes on (the reference's `.cuda()`, :236-238) -- through
+    ShardFeeder: shard first, pinned staging, the next batch's copy under this batch's kernels.
 
     With an initialised process group each rank embeds its contiguous shard of every pair batch and ONE
     all-gather (RCCL) of the packed [f1_new | f2_new | f1 | f2] rows precedes scoring, so every rank returns the
@@ -178,29 +297,27 @@ def calculate_distance(data_loader, encoder, recnet=None, flag=0, use_flip=False
     Returns two [n_pairs,3] float64 arrays (score, label, idx): (f_new based, f based); with device_scores=True
     additionally the two fp32 score vectors still on the device.
     """
+    global last_feed_stats
     embed_fn = _embed_of(encoder, recnet)
     rank = dist.get_rank(group) if (dist and dist.is_initialized()) else 0
     world = dist.get_world_size(group) if (dist and dist.is_initialized()) else 1
     s_new, s_old, labels, idxs = [], [], [], []
-    native = engine_of(embed_fn) is not None or bool(getattr(embed_fn, 'native', False))
-    for data in data_loader:
-        img1, img2 = data['img1'], data['img2']
-        if native and use_gpu and not img1.is_cuda:      # lfw_eval.py:236-238; foreign embed functions get the tensors as they are
-            img1, img2 = img1.cuda(non_blocking=True), img2.cuda(non_blocking=True)
-        n = img1.size(0)
-        lo, hi = shard_bounds(n, rank, world)
-        if hi > lo:
-            both = torch.cat((img1[lo:hi], img2[lo:hi]), 0)
+    dev = target_device(embed_fn) if use_gpu else None
+    if dev is not None and hasattr(embed_fn, 'bind'):
+        embed_fn.bind(dev)            # both weight sets in the handle BEFORE the loop: a rank whose first shard is
+    eng = engine_of(embed_fn)         # empty scores with the same function as every other rank
+    feeder = ShardFeeder(data_loader, rank, world, dev)
+    last_feed_stats = feeder.stats
+    for data, both, m, n in feeder:
+        if m:
             f_new, f = embed_fn(both)
-            m = hi - lo
             e = torch.cat((f_new[:m], f_new[m:], f[:m], f[m:]), 1)        # [m, 4*512]
         else:
-            e = torch.zeros((0, 2048), dtype=torch.float32, device=img1.device)
+            e = torch.zeros((0, 2048), dtype=torch.float32, device=dev if dev is not None else data['img1'].device)
         e = all_gather_rows(e, n, group)
         d = e.size(1) // 4
         fn = score_fn
         if fn is None:
-            eng = engine_of(embed_fn)
             fn = eng.cosine_scores if (eng is not None and e.is_cuda) else cosine_scores_torch
         s_new.append(fn(e[:, :d], e[:, d:2 * d]))
         s_old.append(fn(e[:, 2 * d:3 * d], e[:, 3 * d:]))

@@ -125,7 +125,19 @@ class _NativeModule(nn.Module):
             ent = cache[device.index]
         return ent[1]
 
+    def _reject_replica(self, what):
+        if getattr(self, '_is_replica', False):
+            # nn.parallel.data_parallel / DataParallel (models/trainer.py:70-72) replicate the shell per device IN THREADS:
+            # a replica's tensors are new objects on every call, so the packed native copy would be rebuilt (43.8 M
+            # weights through the host) per forward and replica.  The MI355X design is one process per GPU.
+            raise RuntimeError(
+                'ffrnet_amd.%s was called as a torch data_parallel replica.  This package runs ONE PROCESS PER GPU '
+                '(torch.distributed over RCCL; lfw.calculate_distance shards the pair batch itself): call the module '
+                'directly on its own device and pass gpu_ids of length 1 to the reference Trainer (INTEGRATION.md 1)'
+                % what)
+
     def _require_native(self, x, what):
+        self._reject_replica(what)
         if self.training:
             raise NotImplementedError(
                 'ffrnet_amd.%s: only the eval() forward is implemented natively (the reference '
@@ -284,6 +296,7 @@ class RecNet(_NativeModule):
         return ent
 
     def _forward_train(self, input, label):
+        self._reject_replica('RecNet')
         if not self.training:
             raise NotImplementedError('ffrnet_amd.RecNet: forward(input, label) is the train() branch '
                                       '(models/recnet.py:427-429); call .train() first')

@@ -130,12 +130,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _check_dev(t, name, shape_tail=None):
+def _check_dev(t, name, shape_tail=None, device=None):
+    """Boundary check of a tensor handed to the library as a raw pointer.  `device`: the handle's device -- a tensor
+    on ANOTHER GPU is rejected (its pointer would be dereferenced by kernels running on the handle's GPU: peer reads
+    over xGMI at best, a fault at worst; one process per GPU must `torch.cuda.set_device(local_rank)` or pass explicit
+    devices)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError('%s must be a torch.Tensor' % name)
     if not t.is_cuda:
         raise RuntimeError('ffrnet_amd: %s is on %s; the native HIP path needs a ROCm device '
                            'tensor (there is no CPU fallback)' % (name, t.device))
+    if device is not None and t.device.index != device.index:
+        raise RuntimeError('ffrnet_amd: %s is on %s but this Engine lives on %s; move the tensor there (or create the '
+                           'Engine on the tensor\'s device: one process per GPU calls torch.cuda.set_device(local_rank) '
+                           'before anything else)' % (name, t.device, device))
     if t.dtype != torch.float32:
         raise RuntimeError('ffrnet_amd: %s must be float32, got %s' % (name, t.dtype))
     if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
@@ -154,6 +162,7 @@ class Engine(object):
         self._ck(self.lib.ffr_create(C.byref(self._h), self.device.index), create=True)
         self.has_encoder = False
         self.has_recnet = False
+        self._recnet_sig = None      # lfw.pair_embed: signature of the RecNet shell whose weights this handle holds
 
     # -- plumbing -------------------------------------------------------------
     def _ck(self, rc, create=False):
@@ -209,10 +218,11 @@ class Engine(object):
         arr, n, keep = self._descs(state_dict)
         self._ck(self.lib.ffr_load_recnet(self._h, arr, n))
         self.has_recnet = True
+        self._recnet_sig = None      # whoever loaded through a shell records its signature after this call
 
     # -- forward --------------------------------------------------------------
     def encoder_forward(self, x, want_f=True, want_featmap=True):
-        _check_dev(x, 'x')
+        _check_dev(x, 'x', device=self.device)
         if x.dim() != 4 or x.size(1) != 3:
             raise RuntimeError('ffrnet_amd: encoder input must be [N,3,H,W], got %s' % list(x.shape))
         x = x.contiguous()
@@ -232,7 +242,7 @@ class Engine(object):
         return fm, f
 
     def recnet_forward(self, featmap, want_feat_new=True):
-        _check_dev(featmap, 'input')
+        _check_dev(featmap, 'input', device=self.device)
         if featmap.dim() != 4 or tuple(featmap.shape[1:]) != (512, 7, 7):
             c = featmap.size(1) + featmap.size(2) * featmap.size(3) if featmap.dim() == 4 else -1
             # the reference fails in Conv4Space's first conv (models/recnet.py:363)
@@ -251,11 +261,17 @@ class Engine(object):
 
     def embed(self, x, want_f=True, out=None):
         """x[N,3,112,112] -> (f_new[N,512], f[N,512]); `out` = preallocated (f_new, f)."""
-        _check_dev(x, 'x', (3, 112, 112))
+        _check_dev(x, 'x', (3, 112, 112), device=self.device)
         x = x.contiguous()
         n = x.size(0)
         if out is not None:
             f_new, f = out
+            for o, nm in ((f_new, 'out[0]'), (f, 'out[1]')):
+                if o is None:
+                    continue
+                _check_dev(o, nm, device=self.device)
+                if tuple(o.shape) != (n, 512) or not o.is_contiguous():
+                    raise RuntimeError('ffrnet_amd: %s must be a contiguous [%d,512] tensor, got %s' % (nm, n, list(o.shape)))
         else:
             f_new = torch.empty((n, 512), device=x.device, dtype=torch.float32)
             f = torch.empty((n, 512), device=x.device, dtype=torch.float32) if want_f else None
@@ -267,6 +283,8 @@ class Engine(object):
         """img[N,112,112,3] uint8 RGB (device) -> (f_new, f); flip: optional uint8[N] h-flip flags."""
         if not (torch.is_tensor(img) and img.is_cuda and img.dtype == torch.uint8):
             raise RuntimeError('ffrnet_amd: embed_u8 needs a uint8 ROCm device tensor [N,112,112,3]')
+        if img.device.index != self.device.index:
+            raise RuntimeError('ffrnet_amd: img is on %s but this Engine lives on %s' % (img.device, self.device))
         if img.dim() != 4 or tuple(img.shape[1:]) != (112, 112, 3):
             raise RuntimeError('ffrnet_amd: embed_u8 expects [N,112,112,3] (HWC, RGB), got %s' % list(img.shape))
         img = img.contiguous()
@@ -279,8 +297,8 @@ class Engine(object):
         return f_new, f
 
     def cosine_scores(self, a, b):
-        _check_dev(a, 'a')
-        _check_dev(b, 'b')
+        _check_dev(a, 'a', device=self.device)
+        _check_dev(b, 'b', device=self.device)
         if a.shape != b.shape or a.dim() != 2:
             raise RuntimeError('cosine_scores: a and b must both be [n,dim]')
         a, b = a.contiguous(), b.contiguous()
@@ -293,7 +311,7 @@ class Engine(object):
     def lfw_fold_accuracy(self, scores, labels, n_folds=10):
         """Device fold protocol: scores[n] fp32, labels[n] -> (mean accuracy, [(best_thr, acc)] per fold).
         The mean divides by n_folds (the reference hard-codes 10 = its n_folds)."""
-        _check_dev(scores, 'scores')
+        _check_dev(scores, 'scores', device=self.device)
         scores = scores.contiguous()
         lab = labels.to(device=scores.device, dtype=torch.int32).contiguous()
         thr = torch.empty(n_folds, device=scores.device, dtype=torch.float64)
@@ -367,7 +385,7 @@ class Engine(object):
 
     def op_conv3x3(self, x_nhwc, w, bias, slope=None, pad_mode=0, use_wino=True, resid=None):
         """x[N,H,W,cin] device NHWC, w[cout,cin,3,3] / bias / slope host tensors -> out[N,H,W,cout]."""
-        _check_dev(x_nhwc, 'x')
+        _check_dev(x_nhwc, 'x', device=self.device)
         x_nhwc = x_nhwc.contiguous()
         n, hh, ww, cin = x_nhwc.shape
         wh = w.detach().float().cpu().contiguous()
@@ -388,7 +406,7 @@ class Engine(object):
         x_nhwc [G*N,7,7,cin] and da_nhwc [G*N,7,7,cout] device tensors (logical channel counts);
         w [cout,cin,3,3], gamma/beta/slope [cout] host tensors.
         Returns dict(out, dx, dw[cout,cin,3,3], dgamma, dbeta, dslope, running_mean, running_var, mean, invstd)."""
-        _check_dev(x_nhwc, 'x')
+        _check_dev(x_nhwc, 'x', device=self.device)
         gn, hh, ww, cin = x_nhwc.shape
         assert hh == 7 and ww == 7 and gn % G == 0
         cout = w.size(0)
@@ -478,7 +496,7 @@ class Engine(object):
                                                                       'M_channel', 'feat_space', 'feat_channel')):
         """RecNet.forward(input, label) in train() mode on `groups` BatchNorm batches stacked along dim 0.
         Returns the reference's 7-tuple (entries not in `want` are None)."""
-        _check_dev(featmap, 'featmap')
+        _check_dev(featmap, 'featmap', device=self.device)
         featmap = featmap.contiguous()
         n = featmap.size(0)
         if featmap.dim() != 4 or tuple(featmap.shape[1:]) != (512, 7, 7) or n % groups:
@@ -499,7 +517,7 @@ class Engine(object):
         gs = [g.contiguous().float() if g is not None else None for g in grads]
         for g in gs:
             if g is not None:
-                _check_dev(g, 'grad')
+                _check_dev(g, 'grad', device=self.device)
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_train_backward(self._h, slot, *[_ptr(g) for g in gs], self._stream()))
 
@@ -507,21 +525,21 @@ class Engine(object):
 
     def train_export(self, key, out, which='grad'):
         """One entry in torch layout into the device tensor `out` (no host round trip)."""
-        _check_dev(out, 'out')
+        _check_dev(out, 'out', device=self.device)
         assert out.is_contiguous() and out.dtype == torch.float32
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_train_export(self._h, self._WHICH[which], key.encode(), _ptr(out), self._stream()))
         return out
 
     def train_import(self, key, value, which='param'):
-        _check_dev(value, 'value')
+        _check_dev(value, 'value', device=self.device)
         v = value.detach().contiguous().float()
         with torch.cuda.device(self.device):
             self._ck(self.lib.ffr_train_import(self._h, self._WHICH[which], key.encode(), _ptr(v), self._stream()))
 
     def train_losses(self, f_enc, loss_weight=(1, 1, 1, 1), slot=0):
         """The four weighted loss items + accuracy (device tensor [5]) of the forward in `slot` (G = 2)."""
-        _check_dev(f_enc, 'f_enc')
+        _check_dev(f_enc, 'f_enc', device=self.device)
         out = torch.empty(5, device=f_enc.device, dtype=torch.float32)
         lw = (C.c_double * 4)(*[float(x) for x in loss_weight])
         with torch.cuda.device(self.device):
@@ -534,8 +552,8 @@ class Engine(object):
 
     def train_iteration(self, img_non, img_ocl, label, loss_weight=(1, 1, 1, 1)):
         """Encoder + RecNet train forward + losses + zero_grad + backward in one native call -> device tensor [5]."""
-        _check_dev(img_non, 'img_non')
-        _check_dev(img_ocl, 'img_ocl')
+        _check_dev(img_non, 'img_non', device=self.device)
+        _check_dev(img_ocl, 'img_ocl', device=self.device)
         n = img_non.size(0)
         if tuple(img_non.shape[1:]) != (3, 112, 112) or img_ocl.shape != img_non.shape:
             raise RuntimeError('ffrnet_amd: training images must be [N,3,112,112] pairs')
@@ -573,7 +591,7 @@ class Engine(object):
                                                   self._stream()))
 
     def encoder_trunk_nhwc(self, x, n_blocks):
-        _check_dev(x, 'x')
+        _check_dev(x, 'x', device=self.device)
         x = x.contiguous()
         n, _, h, w = x.shape
         chans, div = 64, 1
@@ -587,7 +605,7 @@ class Engine(object):
         return out
 
     def recnet_debug(self, featmap):
-        _check_dev(featmap, 'input', (512, 7, 7))
+        _check_dev(featmap, 'input', (512, 7, 7), device=self.device)
         featmap = featmap.contiguous()
         n, dev = featmap.size(0), featmap.device
         o = dict(ss_space=torch.empty((n, 49, 49), device=dev),
@@ -637,7 +655,7 @@ class GraphedEmbed(object):
         self.captures += 1
 
     def __call__(self, x):
-        _check_dev(x, 'x', (3, 112, 112))
+        _check_dev(x, 'x', (3, 112, 112), device=self.engine.device)
         if x.size(0) != self.n:
             raise RuntimeError('GraphedEmbed was captured for batch %d, got %d' % (self.n, x.size(0)))
         if self.engine.generation() != self.generation:

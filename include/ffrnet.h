@@ -162,7 +162,7 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "wino_fused" (1)      0: Winograd convolutions run as transform kernels around a batched GEMM (round-1 path)
  *   "wf_phased_maxk" (128) largest padded cin for which k_wino_fused transforms its own input
  *   "wf_minblocks" (200)  fewest 32-tile x 64-channel block tiles for which k_wino_fused is used
- *   "wf_halfblocks" (1)   1: below that limit the 16-tile block shape is used when it fills the chip
+ *   "wf_halfblocks" (1)   1: below that limit the 32-tile x 32-channel block shape (NT = 1) is used when it fills the chip
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
  *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
  *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)

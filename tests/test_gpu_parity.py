@@ -297,6 +297,55 @@ def test_encoder_forward_and_trunk_112x96_full_size(engine, state_dicts):
         assert torch.isfinite(fm).all()
 
 
+@pytest.mark.parametrize('B', [256, 512])
+def test_two_call_shell_path_full_size(engine, state_dicts, B):
+    """The path the reference's UNCHANGED calculate_distance takes through the shells (lfw_eval.py:241-244):
+    `featmap, f = encoder(img)` then `f_new, feat_new = recnet(featmap)` -- ffr_encoder_forward (NCHW featmap out)
+    followed by ffr_recnet_forward (NCHW featmap in, f_new + NCHW feat_new out) -- at the benchmark's batch (256) and at
+    the pair batch of configs[3] (512).  Every row of f, f_new and feat_new equals its batch-8 run; 32 rows are held to
+    the oracle, feat_new included; f_new of the two-call path equals the fused ffr_embed's (VERDICT r03 weak #1a)."""
+    sd_e, sd_r = state_dicts
+    xc = synth.synth_images(B, seed=9100 + B)
+    x = xc.cuda()
+    fm, f = engine.encoder_forward(x)
+    f_new, feat_new = engine.recnet_forward(fm)
+    f, f_new, feat_new = f.clone(), f_new.clone(), feat_new.clone()
+    assert tuple(feat_new.shape) == (B, 512, 7, 7) and tuple(f_new.shape) == (B, 512)
+    assert torch.isfinite(f_new).all() and torch.isfinite(feat_new).all()
+    for i in range(0, B, 8):
+        gm, g = engine.encoder_forward(x[i:i + 8].contiguous())
+        g_new, g_feat = engine.recnet_forward(gm)
+        assert rel(f[i:i + 8], g) < 2e-5 and rel(f_new[i:i + 8], g_new) < 2e-5, i
+        assert rel(feat_new[i:i + 8], g_feat) < 2e-5, i
+    e_new, e = engine.embed(x)
+    assert rel(f_new, e_new) < 2e-5 and rel(f, e) < 2e-5
+    # f_new is the 7x7 average of feat_new (models/recnet.py:423)
+    assert rel(feat_new.mean(dim=(2, 3)), f_new) < 2e-5
+    idx = list(range(5, B, B // 32))[:32]
+    with torch.no_grad():
+        r_fm, r_f = O.encoder_forward(sd_e, xc[idx])
+        r_new, r_feat = O.recnet_forward(sd_r, r_fm)
+    assert rel(f[idx], r_f) < REG_TOL and rel(f_new[idx], r_new) < REG_TOL and rel(feat_new[idx], r_feat) < REG_TOL
+
+
+def test_uint8_input_step_full_size(engine):
+    """ffr_embed_u8 at batch 256 -- k_stem's full-size launch shape (data/dataset.py:70-79: BGR swap, one flip decision
+    per pair, ToTensor, Normalize) -- is bit-identical to ffr_embed on the float tensor torch builds from the same
+    bytes (VERDICT r03 weak #1b)."""
+    g = torch.Generator().manual_seed(78)
+    B = 256
+    img = torch.randint(0, 256, (B, 112, 112, 3), generator=g, dtype=torch.uint8)
+    flip = (torch.rand(B // 2, generator=g) < 0.5).repeat_interleave(2).to(torch.uint8)   # one decision per PAIR (dataset.py:76-79)
+    x = img.flip(-1).permute(0, 3, 1, 2).float().div(255)
+    x = (x - 0.5) / 0.5
+    x = torch.where(flip.view(-1, 1, 1, 1).bool(), x.flip(-1), x).contiguous()
+    f_new_a, f_a = engine.embed(x.cuda())
+    f_new_a, f_a = f_new_a.clone(), f_a.clone()
+    f_new_b, f_b = engine.embed_u8(img.cuda(), flip.cuda())
+    assert torch.equal(f_new_a, f_new_b) and torch.equal(f_a, f_b)
+    assert 0 < int(flip.sum()) < B
+
+
 @pytest.mark.parametrize('tag', ['50_ir', '100_ir', '100_ir_se', '152_ir_se'])
 def test_backbone_variants(golden_dir, tag):
     """Backbone(100 | 152, ., 'ir' | 'ir_se') (pretrain/model_ir_se50.py:84-116; the reference defines them, its scripts
@@ -650,7 +699,8 @@ def test_rccl_one_rank_runs_the_product_collectives():
     parameter broadcast; every collective must be the identity."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # a default, as in bench.py main(): dmabuf IPC handles (DESIGN.md 3.4)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], cwd=root, env=env,

@@ -150,6 +150,8 @@ loader = [dict(img1=i1[s:s+8], img2=i2[s:s+8], label=lab[s:s+8], idx=torch.arang
 pn, p = ffrnet_amd.lfw.calculate_distance(loader, counting)
 np.save(sys.argv[4] + '.%%d.npy' %% rank, np.concatenate([pn, p], 1))
 print('calls', rank, calls)
+st = ffrnet_amd.lfw.last_feed_stats
+print('feed', rank, st['batches'], st['shard_bytes'], st['full_batch_bytes'], st['h2d_bytes'])
 # the reference-shaped entry point lfw_eval.get_avg_accuracy(encoder, recnet, data_loader) with two foreign
 # modules (called in the reference's order), default scoring / fold protocol, sharded over the ranks
 class Enc(torch.nn.Module):
@@ -190,6 +192,12 @@ def test_sharded_verification_two_ranks_gloo(tmp_path):
     pn, p = ffrnet_amd.lfw.calculate_distance(loader, embed)
     assert np.abs(np.concatenate([pn, p], 1) - r0).max() < 1e-5
     assert 'calls 0 [8, 8, 6]' in logs[0] and 'calls 1 [8, 8, 4]' in logs[1]
+    # the input side: a rank slices its shard on the host before anything else happens to the images, so the bytes it
+    # handles are its shard's (2 images per pair x 4 B x 3*112*112), never the whole pair batch's
+    img = 3 * 112 * 112 * 4
+    for r, pairs in ((0, 4 + 4 + 3), (1, 4 + 4 + 2)):
+        line = [ln for ln in logs[r].splitlines() if ln.startswith('feed %d' % r)][0].split()
+        assert [int(v) for v in line[2:]] == [3, 2 * pairs * img, 2 * 21 * img, 0], line
     # get_avg_accuracy(encoder, recnet, loader): same numbers on both ranks and as the single-process protocol
     a_new = ffrnet_amd.lfw.get_accuracy_from_predicts(pn, 3)[0]
     a_old = ffrnet_amd.lfw.get_accuracy_from_predicts(p, 3)[0]
@@ -254,3 +262,75 @@ def test_gradient_averaging_two_ranks():
     for rank, head, total in res:
         assert head == [0.0, 1.5, 3.0, 4.5]
         assert abs(total - 1.5 * 999 * 1000 / 2) < 1e-3
+
+
+class _FakeDeviceTensor(object):
+    """Stands in for a tensor on a GPU this container does not have: _check_dev only looks at type, device, dtype, shape."""
+
+    def __new__(cls, index, shape=(2, 3, 112, 112)):
+        from unittest import mock
+        t = mock.Mock(spec=torch.Tensor)
+        t.is_cuda, t.device, t.dtype, t.shape = True, torch.device('cuda', index), torch.float32, torch.Size(shape)
+        return t
+
+
+def test_boundary_rejects_tensors_of_another_device():
+    """VERDICT r03 #7: a tensor that lives on GPU 0 handed to the handle of GPU 3 must raise, not run."""
+    here, there = _FakeDeviceTensor(3), _FakeDeviceTensor(0)
+    native._check_dev(here, 'x', (3, 112, 112), device=torch.device('cuda', 3))
+    with pytest.raises(RuntimeError, match=r'cuda:0 but this Engine lives on cuda:3'):
+        native._check_dev(there, 'x', (3, 112, 112), device=torch.device('cuda', 3))
+    # every Engine method that takes a device tensor passes its own device to the check
+    src = open(os.path.join(ROOT, 'ffr-net_amd', 'native.py')).read()
+    body = src.split('class Engine(object):', 1)[1]
+    calls = re.findall(r'_check_dev\((.*)\)', body)
+    assert len(calls) >= 18 and all('device=self.device' in c or 'device=self.engine.device' in c for c in calls), calls
+    # out= buffers of Engine.embed get the same check (no GPU: run the method body against a stub handle)
+    eng = native.Engine.__new__(native.Engine)
+    eng.device = torch.device('cuda', 3)
+    x = _FakeDeviceTensor(3)
+    x.contiguous.return_value, x.size.return_value = x, 2
+    with pytest.raises(RuntimeError, match=r'out\[0\] is on cuda:0'):
+        eng.embed(x, out=(_FakeDeviceTensor(0, (2, 512)), _FakeDeviceTensor(3, (2, 512))))
+    eng._h = None       # __del__ -> close() finds nothing to destroy
+
+
+def test_shells_refuse_data_parallel_replicas():
+    """models/trainer.py:70-72 wraps every call in nn.parallel.data_parallel; with more than one gpu id torch replicates
+    the module per device in threads.  The shells state the one-process-per-GPU rule instead of silently re-packing
+    all weights per replica and forward."""
+    for shell, arg in ((ffrnet_amd.Backbone(50, 0.6, 'ir_se'), torch.zeros(1, 3, 112, 112)),
+                       (ffrnet_amd.RecNet(), torch.zeros(1, 512, 7, 7))):
+        shell.eval()
+        rep = shell._replicate_for_data_parallel()
+        with pytest.raises(RuntimeError, match='ONE PROCESS PER GPU'):
+            rep(arg)
+    rep = ffrnet_amd.RecNet().train()._replicate_for_data_parallel()
+    with pytest.raises(RuntimeError, match='ONE PROCESS PER GPU'):
+        rep(torch.zeros(1, 512, 7, 7), torch.zeros(1, dtype=torch.long))
+    # the original (non-replica) module still fails for the documented reason only: no CPU path
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ffrnet_amd.RecNet().eval()(torch.zeros(1, 512, 7, 7))
+
+
+def test_shard_feeder_slices_before_it_copies():
+    """ShardFeeder on host tensors without a device: every rank is handed exactly its contiguous shard, in loader order,
+    ragged last batch and empty shards included."""
+    i1 = torch.arange(21 * 3 * 4 * 4, dtype=torch.float32).reshape(21, 3, 4, 4)
+    i2 = -i1
+    loader = [dict(img1=i1[s:s + 8], img2=i2[s:s + 8], label=torch.zeros(8), idx=torch.arange(8)) for s in (0, 8, 16)]
+    world = 4
+    seen = [[] for _ in range(world)]
+    for r in range(world):
+        fd = ffrnet_amd.lfw.ShardFeeder(loader, r, world, device=None)
+        for (data, both, m, n), s0 in zip(fd, (0, 8, 16)):
+            lo, hi = ffrnet_amd.lfw.shard_bounds(n, r, world)
+            assert m == hi - lo
+            if m:
+                assert torch.equal(both[:m], i1[s0 + lo:s0 + hi]) and torch.equal(both[m:], i2[s0 + lo:s0 + hi])
+                seen[r].append((s0 + lo, s0 + hi))
+            else:
+                assert both is None
+        assert fd.stats['batches'] == 3 and fd.stats['h2d_bytes'] == 0
+        assert fd.stats['shard_bytes'] == 2 * sum(b - a for a, b in seen[r]) * 3 * 4 * 4 * 4
+    assert sorted(x for r in seen for a, b in r for x in range(a, b)) == list(range(21))

@@ -27,6 +27,7 @@ python3 bench.py --workload train > "$O/${RD}_train_step.json" 2>> "$O/bench.err
 python3 tools/wf_trace.py 2>&1 | grep "wf trace" > "$O/${RD}_wino_fused_phase_trace.txt" || true
 TRACE=igemm_trace python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > "$O/${RD}_igemm_trace.txt" || true
 cd /tmp && export TMPDIR=/tmp
+export FFR_BENCH_LIVE_PMC=0      # runs under rocprofv3 never start profiler passes of their own (bench.py also detects the profiler)
 for b in 256 128 64; do
   rocprofv3 --kernel-trace --stats -d "$O/prof$b" -o p --output-format csv -- python3 "$R/bench.py" --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$O/${RD}_bench_batch${b}_under_rocprof.json" 2>/dev/null || true
   cp -- "$O/prof$b/p_kernel_stats.csv" "$O/${RD}_bench_batch${b}_kernel_stats.csv" || true
