@@ -138,7 +138,7 @@ def _pmc_fields(d, src):
             'batch': d.get('batch', 256), 'source': src}
 
 
-def pmc_traffic(sha, batch=256, live=True):
+def pmc_traffic(sha, batch=256, live=True, workload='embed'):
     """HBM bytes per launch of the dominant kernel and per step from rocprofv3 --pmc passes (tools/pmc_bench.sh:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane
     streams on gfx950).  PMC counters cannot be read from inside this process: the committed summary of the round
@@ -148,13 +148,14 @@ def pmc_traffic(sha, batch=256, live=True):
     the GPU busy under the measurements that follow), with the profiler's own environment stripped.  Never nested:
     when this process itself runs under rocprofv3 the figure is reported as absent instead."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.json')), reverse=True):
+    pat = 'r*_pmc_hbm_traffic.json' if workload == 'embed' else 'r*_pmc_%s_traffic.json' % workload
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
         except Exception:
             continue
-        if d.get('so_sha256') == sha and 'dominant' in d and d.get('batch', 256) == batch:
+        if d.get('so_sha256') == sha and 'dominant' in d and d.get('batch', 256) == batch and d.get('workload', 'embed') == workload:
             rel = os.path.relpath(path, ROOT)
             return _pmc_fields(d, '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same build: sha256 %s..., batch %d)'
                                % (rel, sha[:12], batch))
@@ -166,7 +167,8 @@ def pmc_traffic(sha, batch=256, live=True):
         env = {k: v for k, v in os.environ.items()
                if not k.startswith(('ROCP_', 'ROCPROF', 'ROCPROFILER_')) and k not in ('LD_PRELOAD', 'HSA_TOOLS_LIB',
                                                                                         'RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
-        env.update(GRAFT_REPO_ROOT=ROOT, FFR_PMC_BATCH=str(batch), FFR_PMC_PASS_TIMEOUT='110', FFR_BENCH_LIVE_PMC='0')
+        env.update(GRAFT_REPO_ROOT=ROOT, FFR_PMC_BATCH=str(batch), FFR_PMC_PASS_TIMEOUT='110', FFR_BENCH_LIVE_PMC='0',
+                   FFR_PMC_WORKLOAD=workload)
         proc = None
         try:
             proc = subprocess.Popen(['bash', os.path.join(ROOT, 'tools', 'pmc_bench.sh')], env=env, cwd=ROOT,
@@ -176,7 +178,7 @@ def pmc_traffic(sha, batch=256, live=True):
                 raise RuntimeError('tools/pmc_bench.sh exited with %d' % rc)
             with open(os.path.join(ROOT, 'gpurun_out', 'pmc_bench', 'summary.json')) as f:
                 d = json.load(f)
-            if d.get('so_sha256') == sha and 'dominant' in d and d.get('batch', 256) == batch:
+            if d.get('so_sha256') == sha and 'dominant' in d and d.get('batch', 256) == batch and d.get('workload', 'embed') == workload:
                 return _pmc_fields(d, 'measured in this run: tools/pmc_bench.sh as child processes (rocprofv3 --pmc, %.0f s); '
                                       'no committed summary matches this build (sha256 %s...) and batch %d'
                                    % (time.perf_counter() - t0, sha[:12], batch))
@@ -322,6 +324,35 @@ def lfw_protocol_line(eng, dev):
                     '(tests/test_gpu_parity.py::test_lfw_protocol_6000_pairs_matches_reference holds that)'}
 
 
+def cpu_baseline_train(budget_s=15.0):
+    """The training iteration of the oracle (oracle/ffr_oracle_train.py: stock-torch CPU autograd restatement of
+    models/trainer.py:139-187) on the host cores: 8 pairs per iteration, one warm-up iteration, then whole iterations
+    for about budget_s."""
+    import torch
+    from ffrnet_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ffr_oracle_train as OT
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    spec_e, spec_r = state_dict_specs()
+    sd_e, sd_r = synth.synth_state_dict(spec_e), synth.synth_state_dict(spec_r)
+    nb = 8
+    cn, co, cl = synth.synth_train_batch(nb, seed=11)
+    opt = OT.new_adam_state(sd_r)
+    OT.train_step(sd_e, sd_r, opt, cn, co, cl, lr=1e-3)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        OT.train_step(sd_e, sd_r, opt, cn, co, cl, lr=1e-3)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s:
+            break
+    return {'value': round(n * nb / dt, 2), 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d iterations of %d pairs (clean + occluded image each), %.1f s, torch %s CPU autograd '
+                      '(oracle/ffr_oracle_train.py), %d threads' % (n, nb, dt, torch.__version__, cores),
+            'cpu_model': cpu_model()}
+
+
 def train_workload(args, world, rank, local, dist):
     """Secondary workload (SURVEY 8 row N3 / BASELINE configs[4]): whole training iterations through NativeTrainer."""
     import torch
@@ -372,23 +403,41 @@ def train_workload(args, world, rank, local, dist):
     if rank == 0 and not args.no_roofline:
         st = eng.profile_read()
         eng.profile_enable(False)
+        sha = so_sha256()
         cls = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches_per_step': v['launches'] // nprof,
-                   'executed_tflops': round(v['flops_executed'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] else None}
+                   'executed_tflops': round(v['flops_executed'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] and v['flops_executed'] else None}
                for k, v in st.items() if v['launches']}
         dom = st['wino_fused']
-        dom_tf = dom['flops_executed'] / (dom['ms'] * 1e-3) / 1e12 if dom['ms'] else 0.0
+        dom_s = dom['ms'] * 1e-3
+        dom_tf = dom['flops_executed'] / dom_s / 1e12 if dom['ms'] else 0.0
+        dom_useful_tf = dom['flops_useful'] / dom_s / 1e12 if dom['ms'] else 0.0
         mf = [st[k] for k in ('wino_fused', 'conv_igemm', 'wgrad')]
         mf_ms = sum(v['ms'] for v in mf)
         mf_tf = sum(v['flops_executed'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
+        mf_useful_tf = sum(v['flops_useful'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
+        tot_ms = sum(v['ms'] for v in st.values()) / nprof
+        tr_pmc = pmc_traffic(sha, batch=B, live=False, workload='train')
         roof = {'bound': 'mfma', 'kernel': 'k_wino_fused (frozen encoder + RecNet forward + data gradients)',
                 'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                'frac_useful': round(dom_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                'traffic': tr_pmc.get('hbm_bytes_per_launch'), 'traffic_detail': tr_pmc,
                 'avg_launch_us': round(dom['ms'] * 1e3 / max(1, dom['launches']), 2),
                 'mfma_kernels': {'kernels': 'k_wino_fused + k_igemm/k_gemm_stream + k_wgrad', 'executed_tflops': round(mf_tf, 2),
-                                 'frac': round(mf_tf / PEAK_FP32_MFMA_TFLOPS, 4), 'ms_per_step': round(mf_ms / nprof, 3)},
+                                 'frac': round(mf_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 'frac_useful': round(mf_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 'ms_per_step': round(mf_ms / nprof, 3)},
+                'hbm_kernels_ms_per_step': round(tot_ms - mf_ms / nprof, 3),
+                'all_kernels_ms_per_step': round(tot_ms, 3),
                 'per_class': cls,
-                'note': 'instrumented launches only (the convolution / GEMM / weight-gradient kernels and the inference-path '
-                        'classes); BatchNorm, loss and optimiser kernels are HBM-bound and not itemised'}
+                'note': 'every launch of the iteration is instrumented (hipEvent pairs on the launch stream): the inference-path '
+                        'classes (encoder), wgrad, and train_bn (BatchNorm statistics / apply / backward), train_loss (loss items, '
+                        'CosFace head), train_optim (zero_grad, clip + Adam), train_xform (Winograd weight / gradient transforms, '
+                        'dgrad packing, reflection folds), train_elem (remaining elementwise / layout kernels); the classes add up '
+                        'to all_kernels_ms_per_step, which contains the dispatch gaps and is slightly more than ms_per_step'}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_train()
     if rank == 0:
         print(json.dumps({
             'metric': 'training image pairs/sec (frozen IR-SE50 encoder + RecNet forward/backward + CosFace head + clip + Adam)',
@@ -398,7 +447,7 @@ def train_workload(args, world, rank, local, dist):
             'config': {'workload': 'configs[4]: training step, %d pairs per GPU, 112x112x3 fp32' % B,
                        'pairs_per_gpu': B, 'global_pairs': world * B,
                        'parallelism': 'data parallel x%d, one RCCL all-reduce of the flat fp32 gradient buffer per step' % world},
-            'roofline': roof, 'cpu_baseline': None}))
+            'roofline': roof, 'cpu_baseline': cpu}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -551,25 +600,44 @@ def main():
         wf, ig, wn = st['wino_fused'], st['conv_igemm'], st['wino']
         tot_ms = sum(v['ms'] for v in st.values())
         dom = wf if wf['launches'] else ig
-        dom_tf = dom['flops_executed'] / (dom['ms'] * 1e-3) / 1e12          # what the matrix cores executed
+        dom_s = dom['ms'] * 1e-3
+        dom_tf = dom['flops_executed'] / dom_s / 1e12          # what the matrix cores executed
+        dom_useful_tf = dom['flops_useful'] / dom_s / 1e12     # ... without tile / row / channel padding
         mf_ms = wf['ms'] + ig['ms']
         mf_tf = (wf['flops_executed'] + ig['flops_executed']) / (mf_ms * 1e-3) / 1e12
+        mf_useful_tf = (wf['flops_useful'] + ig['flops_useful']) / (mf_ms * 1e-3) / 1e12
         hbm = {k: v for k, v in st.items() if k not in ('wino_fused', 'conv_igemm') and v['launches']}
         hbm_ms = sum(v['ms'] for v in hbm.values())
         hbm_bytes = sum(v['bytes'] for v in hbm.values())
+        step_s = tot_ms / nprof * 1e-3
         step_exec = sum(v['flops_executed'] for v in st.values()) / nprof
+        step_useful = sum(v['flops_useful'] for v in st.values()) / nprof
+        compulsory_gb = sum(v['bytes'] for v in st.values()) / nprof / 1e9
+        alg_tf = value / world * GFLOP_PER_IMAGE / 1e3          # embeddings/s x 15.1427 GFLOP
+        tr = pmc_traffic(sha, batch=B, live=(world == 1))   # child profiler passes only when no other rank waits on this one
+        ratio = round(tr['hbm_gb_per_step_all_kernels'] / compulsory_gb, 3) if tr.get('hbm_gb_per_step_all_kernels') else None
         roof = {'bound': 'mfma',
                 'kernel': 'k_wino_fused (the 36 fp32-MFMA GEMMs + output transform + epilogue of a Winograd F(4x4,3x3) '
                           'convolution in one launch)',
                 'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                'traffic': pmc_traffic(sha, batch=B, live=(world == 1)),   # child profiler passes only when no other rank waits on this one
-                'note': 'achieved = FLOPs the matrix cores EXECUTED in k_wino_fused (2*36*tiles*cin*cout, padding '
-                        'included) / its hipEvent time; the algorithmic direct-convolution FLOPs of those layers are '
-                        '4x (3.06x on 7x7 maps) larger: effective_tflops_algorithmic',
+                # the roofline fraction three ways, all for the dominant kernel over its own hipEvent time:
+                'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),                       # FLOPs EXECUTED, padding included
+                'frac_useful': round(dom_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),          # executed minus tile / row / channel padding
+                'frac_algorithmic_survey_8d': round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),  # whole step, direct-convolution count
+                'traffic': tr.get('hbm_bytes_per_launch'),              # HBM bytes per launch of the dominant kernel (PMC), or null
+                'traffic_ratio_vs_compulsory': ratio,                   # all kernels: PMC bytes per step / compulsory bytes per step
+                'note': 'frac: FLOPs the matrix cores EXECUTED in k_wino_fused (2*36*ceil(T/32)*32*cin_pad*cout_pad per launch) / its '
+                        'hipEvent time / peak.  frac_useful: the same without padding (tiles hanging over 14x14 and 7x7 maps, '
+                        'rows beyond T, zero-padded channels) = the direct-convolution FLOPs of those layers / 4.  '
+                        'frac_algorithmic_survey_8d: embeddings/s x 15.1427 GFLOP (SURVEY 8d counts every convolution as a '
+                        'direct one) / peak for the WHOLE step; it exceeds 1 because Winograd F(4x4,3x3) executes 36 instead of '
+                        '144 multiplies per 4x4 output tile and channel pair (results verified in this process: parity_checked)',
                 'launches_per_step': dom['launches'] // nprof,
                 'avg_launch_us': round(dom['ms'] * 1e3 / max(1, dom['launches']), 2),
                 'gflop_executed_per_launch': round(dom['flops_executed'] / max(1, dom['launches']) / 1e9, 3),
+                'gflop_useful_per_launch': round(dom['flops_useful'] / max(1, dom['launches']) / 1e9, 3),
+                'compulsory_gb_per_step': round(compulsory_gb, 3),
+                'traffic_detail': tr,
                 # what the kernel is co-limited by: operand fragments streamed L2 -> registers; a 32x64 tile
                 # per xi and 8-channel chunk moves (32 + 64) * 8 * 4 bytes for 2 * 32 * 64 * 8 flops
                 'operand_stream': {'bytes_per_flop': 0.09375,
@@ -584,16 +652,20 @@ def main():
                 'per_bound': {
                     'mfma': {'kernels': 'k_wino_fused + k_igemm (stride-2 convs, 1x1 shortcuts, FC)',
                              'executed_tflops': round(mf_tf, 2), 'frac': round(mf_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                             'frac_useful': round(mf_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
                              'ms_per_step': round(mf_ms / nprof, 3)},
                     'hbm': {'kernels': 'k_wino_in_c, k_combine, k_se_*, k_stem, RecNet operators, layout',
                             'compulsory_gb_per_step': round(hbm_bytes / nprof / 1e9, 3),
                             'achieved_tbs': round(hbm_bytes / (hbm_ms * 1e-3) / 1e12, 3) if hbm_ms else None,
                             'frac': round(hbm_bytes / (hbm_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if hbm_ms else None,
                             'ms_per_step': round(hbm_ms / nprof, 3)},
-                    'whole_step': {'executed_tflops': round(step_exec / (tot_ms / nprof * 1e-3) / 1e12, 2),
-                                   'frac_of_mfma_peak': round(step_exec / (tot_ms / nprof * 1e-3) / 1e12
-                                                              / PEAK_FP32_MFMA_TFLOPS, 4)}},
-                'effective_tflops_algorithmic': round(value / world * GFLOP_PER_IMAGE / 1e3, 2),
+                    'whole_step': {'executed_tflops': round(step_exec / step_s / 1e12, 2),
+                                   'frac_of_mfma_peak': round(step_exec / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'frac_useful': round(step_useful / step_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                    'note': 'ms_per_step figures are sums of per-launch hipEvent pairs: each pair also contains the dispatch gap '
+                            'in front of its launch, so the classes add up to all_kernels_ms_per_step, which is slightly MORE '
+                            'than the back-to-back ms_per_step of the timed region'},
+                'effective_tflops_algorithmic': round(alg_tf, 2),
                 'kernel_ms_per_step': {k: round(v['ms'] / nprof, 3) for k, v in st.items() if v['launches']},
                 'all_kernels_ms_per_step': round(tot_ms / nprof, 3),
                 'so_sha256': sha}

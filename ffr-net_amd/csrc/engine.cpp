@@ -277,7 +277,7 @@ void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, i
 
 
 // plan + launch one (possibly batched) implicit-GEMM described by `a` (M, nkt, cout_pad, nbatch set)
-int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st) {
+int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse) {
     int tile, nblocks;
     plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, c.tile, h->opt.sk_minunits, &tile, &nblocks, &a.granule);
     int bm, bn;
@@ -322,7 +322,7 @@ int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, doubl
 #endif
     {
         const double fexec = 2.0 * a.nbatch * (double)a.mtiles * bm * (double)a.cout_pad * a.KK;
-        Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes, fexec);
+        Scope s(h, st, FFR_KC_CONV_IGEMM, flops, bytes, fexec, fuse);
         HIPCK(h, launch_igemm(a, tile, nblocks, st));
     }
     return FFR_OK;
@@ -464,7 +464,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 return FFR_OK;
             }
 #endif
-            Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec);
+            Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec, flops / 4.0);
             HIPCK(h, launch_wino_fused(f, st));
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
             return FFR_OK;
@@ -526,7 +526,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     igemm_tile_shape(gtile, &bm, &bn);
                     const double fexec = 2.0 * 36.0 * (double)((Ts + bm - 1) / bm) * bm * (double)L.cout_pad * L.cin_pad;
                     // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
-                    Scope s(h, st, FFR_KC_CONV_IGEMM, flops / nslice, bytes / nslice, fexec);
+                    Scope s(h, st, FFR_KC_CONV_IGEMM, flops / nslice, bytes / nslice, fexec, flops / nslice / 4.0);
                     HIPCK(h, launch_gemm_stream(g, gtile, gblocks, st));
                 } else {
                 IgemmArgs g{};
@@ -539,7 +539,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 g.nbatch = 36;
                 g.x_bstride = Ts * L.cin_pad; g.w_bstride = (long long)L.cout_pad * L.cin_pad; g.out_bstride = Ts * L.cout_pad;
                 // the roofline numerator stays the DIRECT convolution's algorithmic FLOPs
-                RC(run_gemm(h, g, c, flops / nslice, bytes / nslice, st));
+                RC(run_gemm(h, g, c, flops / nslice, bytes / nslice, st, flops / nslice / 4.0));
                 }
                 if (c.wino_stage == 1) continue;        // the caller transforms M itself (k_wino_out_in)
                 Scope s(h, st, FFR_KC_WINO, 0, 4.0 * (36.0 * Ts * L.cout_pad + (double)M / nslice * L.cout));
@@ -1273,7 +1273,7 @@ int ffr_profile_enable(ffr_handle* h, int on) {
 
 int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
     if (!h || !out) return fail(h, FFR_ERR_ARG, "ffr_profile_read: bad arguments");
-    for (int i = 0; i < FFR_KC_COUNT; ++i) out[i] = ffr_kclass_stat{0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < FFR_KC_COUNT; ++i) out[i] = ffr_kclass_stat{0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (auto& r : h->prof_log) {
         HIPCK(h, hipEventSynchronize(r.e1));
         float ms = 0.f;
@@ -1287,6 +1287,7 @@ int ffr_profile_read(ffr_handle* h, ffr_kclass_stat* out) {
             out[r.kc].flops += r.flops;
             out[r.kc].bytes += r.bytes;
             out[r.kc].flops_executed += r.fexec;
+            out[r.kc].flops_useful += r.fuse;
         }
         h->ev_pool.push_back(r.e0);
         h->ev_pool.push_back(r.e1);

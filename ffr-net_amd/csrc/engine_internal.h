@@ -66,7 +66,7 @@ struct Options {
 struct ProfRec {
     hipEvent_t e0, e1;
     int kc;
-    double flops, bytes, fexec;
+    double flops, bytes, fexec, fuse;
     bool side;          // enqueued on the handle's second stream: runs beside a launch of the main stream
 };
 
@@ -144,7 +144,8 @@ struct Scope {
     hipStream_t st;
     ProfRec r;
     bool on;
-    Scope(ffr_handle* h_, hipStream_t st_, int kc, double flops, double bytes, double fexec = -1.0)
+    // fexec: FLOPs the launch executes (default: flops); fuse: the part of them that is not padding (default: flops)
+    Scope(ffr_handle* h_, hipStream_t st_, int kc, double flops, double bytes, double fexec = -1.0, double fuse = -1.0)
         : h(h_), st(st_), on(h_->prof) {
         if (!on) return;
         auto get = [&]() {
@@ -153,7 +154,7 @@ struct Scope {
             else hipEventCreate(&e);
             return e;
         };
-        r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes; r.fexec = fexec < 0 ? flops : fexec;
+        r.e0 = get(); r.e1 = get(); r.kc = kc; r.flops = flops; r.bytes = bytes; r.fexec = fexec < 0 ? flops : fexec; r.fuse = fuse < 0 ? flops : fuse;
         r.side = h->side && st == h->side;
         hipEventRecord(r.e0, st);
     }
@@ -203,7 +204,7 @@ struct ConvCall {
 
 int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long T, double x_bytes, int wino_mode);
 bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap);
-int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st);
+int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse = -1.0);
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st);
 
 struct Arena {

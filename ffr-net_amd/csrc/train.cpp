@@ -7,6 +7,10 @@
 #include "engine_internal.h"
 #include "train_kernels.h"
 
+// One launch of the training step under a profiling scope of its kernel class (ffr_profile_*; bench.py --workload train
+// itemises the step with them).  Costs nothing when profiling is off; `st` is the launch stream of the calling function.
+#define TLAUNCH(kc, call) do { Scope _ps(h, st, kc, 0.0, 0.0); HIPCK(h, call); } while (0)
+
 namespace ffr_eng {
 
 namespace {
@@ -70,7 +74,7 @@ int layer_forward(ffr_handle* h, const Work& w, const TLayer& L, TSaved& sv, int
     int fused = 0;
     if (wino) {
         fused = s.fused ? wino_fused_choice(h, L.cin_pad, L.cout_pad, (long long)G * N * 4, 4.0 * G * N * 49 * sv.x_pitch, s.fused == 2 ? 1 : -1) : 0;
-        HIPCK(h, launch_wino_weights(L.w, s.U, L.cout_pad, L.cin_pad, st, fused ? 1 : 0));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_wino_weights(L.w, s.U, L.cout_pad, L.cin_pad, st, fused ? 1 : 0));
         cw.wu = s.U;
         if (fused) cw.wuc = s.U;
     }
@@ -80,9 +84,9 @@ int layer_forward(ffr_handle* h, const Work& w, const TLayer& L, TSaved& sv, int
     conv_call_common(c, w, wino);
     if (wino) c.wino_mode = fused == 2 ? 3 : (fused == 1 ? 1 : 2);
     RC(run_conv(h, cw, c, st));
-    HIPCK(h, launch_bn_stats(sv.y, L.cout_pad, G, N * 49, L.gamma, L.beta, update_running ? L.rmean : nullptr,
+    TLAUNCH(FFR_KC_TRAIN_BN, launch_bn_stats(sv.y, L.cout_pad, G, N * 49, L.gamma, L.beta, update_running ? L.rmean : nullptr,
                              update_running ? L.rvar : nullptr, BN_MOMENTUM, BN_EPS_F, sv.bn, part, st));
-    HIPCK(h, launch_bn_apply(sv.y, L.cout_pad, G, N * 49, sv.bn, L.slope, resid, res_pitch, out, out_pitch, out_coff, flags, st));
+    TLAUNCH(FFR_KC_TRAIN_BN, launch_bn_apply(sv.y, L.cout_pad, G, N * 49, sv.bn, L.slope, resid, res_pitch, out, out_pitch, out_coff, flags, st));
     return FFR_OK;
 }
 
@@ -93,25 +97,26 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
                    int cin_need, const float* add, int add_pitch, int add_coff, hipStream_t st) {
     const int rows = G * N * 49;
     if ((size_t)rows * L.cout_pad > s.dy_floats) return fail(h, FFR_ERR_NOMEM, "training scratch (dy) too small");
-    HIPCK(h, launch_bn_bwd(da, da_pitch, da_coff, sv.y, L.cout_pad, G, N * 49, sv.bn, L.gamma, L.slope, L.ggamma, L.gbeta,
+    TLAUNCH(FFR_KC_TRAIN_BN, launch_bn_bwd(da, da_pitch, da_coff, sv.y, L.cout_pad, G, N * 49, sv.bn, L.gamma, L.slope, L.ggamma, L.gbeta,
                            L.gslope, accumulate, s.dy, s.part, st));
     const long long T = (long long)G * N * 4;          // 2x2 tiles of 4x4 outputs per 7x7 map
     const bool wino_w = s.wino && L.cin_pad >= 128 && w.winoV && (size_t)36 * T * L.cin_pad <= w.wino_cap &&
                         (size_t)36 * T * L.cout_pad <= w.wino_cap && s.U && (size_t)36 * L.cout_pad * L.cin_pad <= s.U_floats;
     if (wino_w) {
         // weight gradient in the Winograd domain: dU[xi] = dM[xi]^T V[xi] (36 TN GEMMs over the tiles), dW += G^T dU G
-        HIPCK(h, launch_wino_in(sv.x, w.winoV, G * N, 7, 7, sv.x_pitch, L.cin_pad, 1, st));
-        HIPCK(h, launch_wino_dout(s.dy, w.winoM, G * N, 7, 7, L.cout_pad, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_wino_in(sv.x, w.winoV, G * N, 7, 7, sv.x_pitch, L.cin_pad, 1, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_wino_dout(s.dy, w.winoM, G * N, 7, 7, L.cout_pad, st));
         WgradArgs a{};
         a.dy = w.winoM; a.x = w.winoV; a.zero = h->zero; a.rows = (int)T; a.H = 1; a.W = 1; a.x_pitch = L.cin_pad;
         a.dy_pitch = L.cout_pad; a.cin_pad = L.cin_pad; a.taps = 1; a.pad_mode = 0; a.cout_pad = L.cout_pad;
         // dU in the U scratch (free until the data gradient re-derives its weights), split-K slabs in s.slabs
         {
             const double fx = 2.0 * 36.0 * (double)T * L.cout_pad * L.cin_pad;
-            Scope sc(h, st, FFR_KC_WGRAD, 2.0 * rows * 9.0 * L.cout * L.cin, 4.0 * 36.0 * T * (L.cout_pad + L.cin_pad), fx);
+            Scope sc(h, st, FFR_KC_WGRAD, 2.0 * rows * 9.0 * L.cout * L.cin, 4.0 * 36.0 * T * (L.cout_pad + L.cin_pad), fx,
+                     2.0 * rows * 9.0 * L.cout * L.cin / 4.0);
             HIPCK(h, launch_wgrad_batched(a, s.U, 36, T * L.cout_pad, T * L.cin_pad, s.slabs, s.slab_floats, st));
         }
-        HIPCK(h, launch_wino_dweights(s.U, L.gw, L.cout_pad, L.cin_pad, accumulate, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_wino_dweights(s.U, L.gw, L.cout_pad, L.cin_pad, accumulate, st));
     } else {
         WgradArgs a{};
         a.dy = s.dy; a.x = sv.x; a.zero = h->zero; a.rows = rows; a.H = 7; a.W = 7; a.x_pitch = sv.x_pitch;
@@ -124,7 +129,7 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
     const int need_pad = round_up(cin_need, 64);
     if ((size_t)need_pad * 9 * L.cout_pad > s.wd_floats) return fail(h, FFR_ERR_NOMEM, "training scratch (wd) too small");
     if ((size_t)G * N * 81 * need_pad > s.dxp_floats) return fail(h, FFR_ERR_NOMEM, "training scratch (dxp) too small");
-    HIPCK(h, launch_pack_dgrad(L.w, L.cout_pad, L.cin_pad, s.wd, need_pad, st));
+    TLAUNCH(FFR_KC_TRAIN_XFORM, launch_pack_dgrad(L.w, L.cout_pad, L.cin_pad, s.wd, need_pad, st));
     ConvW cw;
     cw.cin = L.cout_pad; cw.cin_pad = L.cout_pad; cw.cout = need_pad; cw.cout_pad = need_pad; cw.R = 3; cw.S = 3;
     cw.stride = 1; cw.pad = 2; cw.pad_mode = 0; cw.border = 0; cw.w = s.wd; cw.bias = h->zero; cw.slope = nullptr; cw.wu = nullptr;
@@ -140,8 +145,8 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
         // (1,1) of an 8x8 map (2x2 tiles instead of the 3x3 a 9x9 output would need), row 8 and column 8 (only the last
         // weight row / column reaches them) as two GEMMs with K = 3*cout.
         const int fused = s.fused ? wino_fused_choice(h, L.cout_pad, need_pad, (long long)imgs * 4, 4.0 * imgs * 64 * L.cout_pad, s.fused == 2 ? 1 : -1) : 0;
-        HIPCK(h, launch_wino_weights(s.wd, s.U, need_pad, L.cout_pad, st, fused ? 1 : 0));
-        HIPCK(h, launch_embed_8x8(s.dy, s.canvas, imgs, L.cout_pad, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_wino_weights(s.wd, s.U, need_pad, L.cout_pad, st, fused ? 1 : 0));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_embed_8x8(s.dy, s.canvas, imgs, L.cout_pad, st));
         cw.wu = s.U; cw.pad = 1;
         if (fused) cw.wuc = s.U;
         c.x = s.canvas; c.H = 8; c.W = 8;
@@ -154,18 +159,18 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
         float* Wr = s.edgeW + (size_t)need_pad * 3 * L.cout_pad;
         float* Ob = s.edgeO;
         float* Or = s.edgeO + (size_t)imgs * 9 * need_pad;
-        HIPCK(h, launch_dgrad_edges(s.dy, Eb, Er, imgs, L.cout_pad, st));
-        HIPCK(h, launch_pack_dgrad_edges(L.w, L.cout_pad, L.cin_pad, Wb, Wr, need_pad, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_dgrad_edges(s.dy, Eb, Er, imgs, L.cout_pad, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_pack_dgrad_edges(L.w, L.cout_pad, L.cin_pad, Wb, Wr, need_pad, st));
         RC(gemm_rows(h, w, Eb, 3 * L.cout_pad, 3 * L.cout_pad, Wb, nullptr, need_pad, Ob, need_pad, (long long)imgs * 9, nullptr, 0, 0, st));
         RC(gemm_rows(h, w, Er, 3 * L.cout_pad, 3 * L.cout_pad, Wr, nullptr, need_pad, Or, need_pad, (long long)imgs * 8, nullptr, 0, 0, st));
-        HIPCK(h, launch_fold_reflect3(s.dxp, Ob, Or, need_pad, imgs, round_up(cin_need, 4), add, add_pitch, add_coff, dx, dx_pitch,
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_fold_reflect3(s.dxp, Ob, Or, need_pad, imgs, round_up(cin_need, 4), add, add_pitch, add_coff, dx, dx_pitch,
                                       dx_coff, st));
         return FFR_OK;
     }
     conv_call_common(c, w, false);
     RC(run_conv(h, cw, c, st));
     const int cfold = round_up(cin_need, 4);
-    HIPCK(h, launch_fold_reflect(s.dxp, need_pad, G * N, cfold, add, add_pitch, add_coff, dx, dx_pitch, dx_coff, st));
+    TLAUNCH(FFR_KC_TRAIN_XFORM, launch_fold_reflect(s.dxp, need_pad, G * N, cfold, add, add_pitch, add_coff, dx, dx_pitch, dx_coff, st));
     return FFR_OK;
 }
 
@@ -435,9 +440,9 @@ int get_train(ffr_handle* h, TrainState** t) {
 int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream_t st) {
     const int G = c.G, N = c.N, imgs = G * N, rows = imgs * 49;
     const long long crow = (long long)imgs * 512;
-    HIPCK(h, launch_copy_slice(c.X, c.bufS, rows, 512, 576, 0, st));
-    HIPCK(h, launch_copy_slice(c.X, c.bufM, rows, 512, 1536, 1024, st));
-    HIPCK(h, launch_selfsim_space(c.X, c.bufS, 576, nullptr, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_copy_slice(c.X, c.bufS, rows, 512, 576, 0, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_copy_slice(c.X, c.bufM, rows, 512, 1536, 1024, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_selfsim_space(c.X, c.bufS, 576, nullptr, imgs, st));
     t->nbt += G;      // num_batches_tracked: every BatchNorm of the net sees G batches per call
     auto L = [&](const TLayer& Ly, TSaved& sv, const float* x, int x_pitch, const float* resid, int res_pitch, float* out,
                  int out_pitch, int out_coff, int flags) -> int {
@@ -454,35 +459,35 @@ int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream
     RC(L(t->sp[6], c.sp[6], c.out_sp[5], 128, nullptr, 0, c.out_sp[6], 64, 0, 0));
     RC(L(t->sp[7], c.sp[7], c.out_sp[6], 64, nullptr, 0, c.out_sp[7], 64, 0, 0));
     RC(L(t->sp[8], c.sp[8], c.out_sp[7], 64, c.out_sp[6], 64, c.ms, 64, 0, 1));
-    HIPCK(h, launch_space_apply(c.X, c.ms, 64, c.bufM, 1536, 0, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_space_apply(c.X, c.ms, 64, c.bufM, 1536, 0, imgs, st));
     // Conv4Channel (recnet.py:372-386) on channelF_cat = [ss_channel | X^T] as six GEMMs
-    HIPCK(h, launch_ch_prep(c.X, c.Xt, c.Xht, c.cat, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_ch_prep(c.X, c.Xt, c.Xht, c.cat, imgs, st));
     RC(gemm_batched(h, w, c.Xht, 512 * 64, 64, c.Xht, 512 * 64, 512, c.cat, 576, (long long)512 * 576, 512, imgs, st));
     const Lin* ln = t->lin;
     RC(gemm_rows(h, w, c.cat, 576, 576, ln[0].w, ln[0].b, 64, c.h1pre, 64, crow, nullptr, 0, 0, st));
-    HIPCK(h, launch_prelu_rows(c.h1pre, c.h1, 64, 64, t->a[0], crow, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_prelu_rows(c.h1pre, c.h1, 64, 64, t->a[0], crow, st));
     c.folded = t->sc.fold;
     if (c.folded) {
         // Linear(32,512) -> Linear(512,32) pairs as their 32x32 product (exact algebra, as the inference kernel does)
-        HIPCK(h, launch_ch_fold(ln[2].w, ln[2].b, ln[1].w, ln[1].b, t->foldA[0], t->foldd[0], st));
-        HIPCK(h, launch_ch_fold(ln[4].w, ln[4].b, ln[3].w, ln[3].b, t->foldA[1], t->foldd[1], st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_ch_fold(ln[2].w, ln[2].b, ln[1].w, ln[1].b, t->foldA[0], t->foldd[0], st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_ch_fold(ln[4].w, ln[4].b, ln[3].w, ln[3].b, t->foldA[1], t->foldd[1], st));
         RC(gemm_rows(h, w, c.h1, 64, 32, t->foldA[0], t->foldd[0], 64, c.h2pre, 64, crow, nullptr, 0, 0, st));
     } else {
         RC(gemm_rows(h, w, c.h1, 64, 32, ln[1].w, ln[1].b, 512, c.t2, 512, crow, nullptr, 0, 0, st));
         RC(gemm_rows(h, w, c.t2, 512, 512, ln[2].w, ln[2].b, 64, c.h2pre, 64, crow, nullptr, 0, 0, st));
     }
-    HIPCK(h, launch_prelu_rows(c.h2pre, c.h2, 64, 64, t->a[1], crow, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_prelu_rows(c.h2pre, c.h2, 64, 64, t->a[1], crow, st));
     if (c.folded) {
         RC(gemm_rows(h, w, c.h2, 64, 32, t->foldA[1], t->foldd[1], 64, c.h3pre, 64, crow, nullptr, 0, 0, st));
     } else {
         RC(gemm_rows(h, w, c.h2, 64, 32, ln[3].w, ln[3].b, 512, c.t5, 512, crow, nullptr, 0, 0, st));
         RC(gemm_rows(h, w, c.t5, 512, 512, ln[4].w, ln[4].b, 64, c.h3pre, 64, crow, nullptr, 0, 0, st));
     }
-    HIPCK(h, launch_prelu_rows(c.h3pre, c.h3, 64, 64, t->a[2], crow, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_prelu_rows(c.h3pre, c.h3, 64, 64, t->a[2], crow, st));
     RC(gemm_rows(h, w, c.h3, 64, 32, ln[5].w, ln[5].b, 512, c.Mc, 512, crow, nullptr, 0, 1 /*sigmoid*/, st));
     // feat_channel_raw = M_channel @ X (recnet.py:410), flip + cat (:416-417)
     RC(gemm_batched(h, w, c.Mc, (long long)512 * 512, 512, c.X, 49 * 512, 64, c.raw, 64, 512 * 64, 512, imgs, st));
-    HIPCK(h, launch_raw_to_cat(c.raw, c.bufF, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_raw_to_cat(c.raw, c.bufF, imgs, st));
     // ChannelFlipMerge -> bufM[:, 512:1024]; Conv4Merge -> feat_new
     RC(L(t->fm[0], c.fm[0], c.bufF, 1024, nullptr, 0, c.out_fm[0], 512, 0, 0));
     RC(L(t->fm[1], c.fm[1], c.out_fm[0], 512, nullptr, 0, c.out_fm[1], 512, 0, 0));
@@ -490,10 +495,10 @@ int train_forward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, hipStream
     RC(L(t->mg[0], c.mg[0], c.bufM, 1536, nullptr, 0, c.out_mg[0], 512, 0, 0));
     RC(L(t->mg[1], c.mg[1], c.out_mg[0], 512, nullptr, 0, c.out_mg[1], 512, 0, 0));
     RC(L(t->mg[2], c.mg[2], c.out_mg[1], 512, c.out_mg[0], 512, c.featnew, 512, 0, 0));
-    HIPCK(h, launch_avgpool49(c.featnew, c.fnew, imgs, 512, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_avgpool49(c.featnew, c.fnew, imgs, 512, st));
     // CosFace head (recnet.py:254-270)
-    HIPCK(h, launch_row_normalize(c.fnew, 512, c.fn, c.fnorm, imgs, st));
-    HIPCK(h, launch_row_normalize(t->clsW, 512, c.wn, c.wnorm, N_CLASSES, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_row_normalize(c.fnew, 512, c.fn, c.fnorm, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_row_normalize(t->clsW, 512, c.wn, c.wnorm, N_CLASSES, st));
     RC(gemm_rows(h, w, c.fn, 512, 512, c.wn, nullptr, CLS_PAD, c.cosv, CLS_PAD, imgs, nullptr, 0, 0, st));
     c.valid = true;
     return FFR_OK;
@@ -509,13 +514,16 @@ int lin_backward(ffr_handle* h, TrainState* t, const Work& w, const Lin& ln, con
     WgradArgs a{};
     a.dy = dy; a.x = x; a.zero = h->zero; a.rows = (int)rows; a.H = 1; a.W = 1; a.x_pitch = x_pitch; a.dy_pitch = dy_pitch;
     a.cin_pad = ln.in_pad; a.taps = 1; a.pad_mode = 0; a.cout_pad = ln.out_pad;
-    HIPCK(h, launch_wgrad(a, ln.gw, 1, t->sc.slabs, t->sc.slab_floats, st));
-    HIPCK(h, launch_colsum(dy, dy_pitch, (int)rows, ln.out_pad, ln.gb, 1, t->sc.part, st));
+    {
+        Scope sc(h, st, FFR_KC_WGRAD, 2.0 * rows * ln.out * ln.in, 4.0 * rows * (ln.out_pad + ln.in_pad), 2.0 * rows * ln.out_pad * ln.in_pad);
+        HIPCK(h, launch_wgrad(a, ln.gw, 1, t->sc.slabs, t->sc.slab_floats, st));
+    }
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_colsum(dy, dy_pitch, (int)rows, ln.out_pad, ln.gb, 1, t->sc.part, st));
     if (dx) {
         // dx[rows][in] = dy[rows][out] * W  -> the kernel wants W^T as [in rounded to 64][K], K = out (32 or 512)
         const int n_pad = round_up(ln.in_pad, 64);
         const int kb = ln.out <= 32 ? 32 : ln.out_pad;
-        HIPCK(h, launch_transpose_pad(ln.w, kb, ln.in_pad, ln.in_pad, t->wT, n_pad, kb, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_transpose_pad(ln.w, kb, ln.in_pad, ln.in_pad, t->wT, n_pad, kb, st));
         RC(gemm_rows(h, w, dy, dy_pitch, kb, t->wT, nullptr, n_pad, dx, dx_pitch, rows, nullptr, 0, 0, st));
     }
     return FFR_OK;
@@ -534,26 +542,29 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     const float* df = internal ? t->df_ext : og.f_new;
     const float* df_in = df;
     if (internal || og.pred_loss || og.pred_label) {
-        if (!internal) HIPCK(h, launch_cosface_dcos(og.pred_loss, og.pred_label, t->dcos, CLS_PAD, imgs, N_CLASSES, COSFACE_S, st));
-        HIPCK(h, launch_transpose_pad(c.wn, CLS_PAD, 512, 512, t->wnT, 512, CLS_PAD, st));
+        if (!internal) TLAUNCH(FFR_KC_TRAIN_LOSS, launch_cosface_dcos(og.pred_loss, og.pred_label, t->dcos, CLS_PAD, imgs, N_CLASSES, COSFACE_S, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_transpose_pad(c.wn, CLS_PAD, 512, 512, t->wnT, 512, CLS_PAD, st));
         RC(gemm_rows(h, w, t->dcos, CLS_PAD, CLS_PAD, t->wnT, nullptr, 512, t->dfn, 512, imgs, nullptr, 0, 0, st));
         WgradArgs a{};
         a.dy = t->dcos; a.x = c.fn; a.zero = h->zero; a.rows = imgs; a.H = 1; a.W = 1; a.x_pitch = 512; a.dy_pitch = CLS_PAD;
         a.cin_pad = 512; a.taps = 1; a.pad_mode = 0; a.cout_pad = CLS_PAD;
-        HIPCK(h, launch_wgrad(a, t->dwn, 0, s.slabs, s.slab_floats, st));
-        HIPCK(h, launch_normalize_bwd(t->dwn, 512, c.wn, c.wnorm, nullptr, t->gclsW, 512, 1, N_CLASSES, st));
-        HIPCK(h, launch_normalize_bwd(t->dfn, 512, c.fn, c.fnorm, df_in, t->df, 512, 0, imgs, st));
+        {
+            Scope sc(h, st, FFR_KC_WGRAD, 2.0 * imgs * 512.0 * N_CLASSES, 4.0 * imgs * (CLS_PAD + 512.0), 2.0 * imgs * 512.0 * CLS_PAD);
+            HIPCK(h, launch_wgrad(a, t->dwn, 0, s.slabs, s.slab_floats, st));
+        }
+        TLAUNCH(FFR_KC_TRAIN_LOSS, launch_normalize_bwd(t->dwn, 512, c.wn, c.wnorm, nullptr, t->gclsW, 512, 1, N_CLASSES, st));
+        TLAUNCH(FFR_KC_TRAIN_LOSS, launch_normalize_bwd(t->dfn, 512, c.fn, c.fnorm, df_in, t->df, 512, 0, imgs, st));
         df = t->df;
     }
     HIPCK(h, hipEventRecord(t->bucket_ev[4], st));          // classifier.weight gradient is final
-    if (df) HIPCK(h, launch_avgpool_bwd(df, nullptr, t->dFeatNew, imgs, 512, st));
+    if (df) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_avgpool_bwd(df, nullptr, t->dFeatNew, imgs, 512, st));
     else HIPCK(h, hipMemsetAsync(t->dFeatNew, 0, (size_t)rows * 512 * 4, st));
     // external gradients wrt feat_space / feat_channel (NCHW) -> extM [rows][1024]
     if (internal) { /* extM was filled by train_losses */ }
-    else if (og.feat_space) HIPCK(h, launch_nchw_to_nhwc(og.feat_space, t->extM, 1024, imgs, 49, 512, st));
-    else HIPCK(h, launch_fill(t->extM, 0.f, (size_t)rows * 1024, st));
+    else if (og.feat_space) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_nchw_to_nhwc(og.feat_space, t->extM, 1024, imgs, 49, 512, st));
+    else TLAUNCH(FFR_KC_TRAIN_ELEM, launch_fill(t->extM, 0.f, (size_t)rows * 1024, st));
     if (internal) { }
-    else if (og.feat_channel) HIPCK(h, launch_nchw_to_nhwc(og.feat_channel, t->extM + 512, 1024, imgs, 49, 512, st));
+    else if (og.feat_channel) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_nchw_to_nhwc(og.feat_channel, t->extM + 512, 1024, imgs, 49, 512, st));
     else if (og.feat_space) {
         // zero the second half only
         HIPCK(h, hipMemset2DAsync(t->extM + 512, 1024 * 4, 0, 512 * 4, rows, st));
@@ -569,13 +580,13 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
     RC(LB(t->fm[0], c.fm[0], t->d512b, 512, 0, t->dF, 1024, 1024, nullptr, 0, 0));
     HIPCK(h, hipEventRecord(t->bucket_ev[1], st));          // ChannelFlipMerge
     // ---- M_channel: feat_channel_raw = M_channel @ X -------------------------------------------
-    HIPCK(h, launch_cat_to_draw(t->dF, t->dRawt, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_cat_to_draw(t->dF, t->dRawt, imgs, st));
     RC(gemm_batched(h, w, t->dRawt, 512 * 64, 64, c.Xt, 512 * 64, 512, t->dMc, 512, (long long)512 * 512, 512, imgs, st));
-    HIPCK(h, launch_sigmoid_bwd_ext(t->dMc, og.M_channel, c.Mc, (size_t)crow * 512, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_sigmoid_bwd_ext(t->dMc, og.M_channel, c.Mc, (size_t)crow * 512, st));
     // ---- Conv4Channel, last linear first -------------------------------------------------------
     const Lin* ln = t->lin;
     RC(lin_backward(h, t, w, ln[5], t->dMc, 512, c.h3, 64, crow, t->d32a, 64, st));
-    HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h3pre, 64, 64, t->a[2], crow, t->rowdot, t->ga[2], 1, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_prelu_rows_bwd(t->d32a, c.h3pre, 64, 64, t->a[2], crow, t->rowdot, t->ga[2], 1, st));
     // a folded pair: gradient of the 32x32 product, then its adjoint onto the two linears
     auto pair_backward = [&](int q, const Lin& lb, const Lin& la, const float* dy, const float* x, float* dx) -> int {
         Lin f;
@@ -583,7 +594,7 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
         HIPCK(h, hipMemsetAsync(t->gfoldA, 0, 64 * 32 * sizeof(float), st));
         HIPCK(h, hipMemsetAsync(t->gfoldd, 0, 64 * sizeof(float), st));
         RC(lin_backward(h, t, w, f, dy, 64, x, 64, crow, dx, 64, st));
-        HIPCK(h, launch_ch_unfold(t->gfoldA, t->gfoldd, lb.w, la.w, la.b, lb.gw, lb.gb, la.gw, la.gb, st));
+        TLAUNCH(FFR_KC_TRAIN_XFORM, launch_ch_unfold(t->gfoldA, t->gfoldd, lb.w, la.w, la.b, lb.gw, lb.gb, la.gw, la.gb, st));
         return FFR_OK;
     };
     if (c.folded) RC(pair_backward(1, ln[4], ln[3], t->d32a, c.h2, t->d32b));
@@ -591,19 +602,19 @@ int train_backward(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const Ou
         RC(lin_backward(h, t, w, ln[4], t->d32a, 64, c.t5, 512, crow, t->dt, 512, st));
         RC(lin_backward(h, t, w, ln[3], t->dt, 512, c.h2, 64, crow, t->d32b, 64, st));
     }
-    HIPCK(h, launch_prelu_rows_bwd(t->d32b, c.h2pre, 64, 64, t->a[1], crow, t->rowdot, t->ga[1], 1, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_prelu_rows_bwd(t->d32b, c.h2pre, 64, 64, t->a[1], crow, t->rowdot, t->ga[1], 1, st));
     if (c.folded) RC(pair_backward(0, ln[2], ln[1], t->d32b, c.h1, t->d32a));
     else {
         RC(lin_backward(h, t, w, ln[2], t->d32b, 64, c.t2, 512, crow, t->dt, 512, st));
         RC(lin_backward(h, t, w, ln[1], t->dt, 512, c.h1, 64, crow, t->d32a, 64, st));
     }
-    HIPCK(h, launch_prelu_rows_bwd(t->d32a, c.h1pre, 64, 64, t->a[0], crow, t->rowdot, t->ga[0], 1, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_prelu_rows_bwd(t->d32a, c.h1pre, 64, 64, t->a[0], crow, t->rowdot, t->ga[0], 1, st));
     RC(lin_backward(h, t, w, ln[0], t->d32a, 64, c.cat, 576, crow, nullptr, 0, st));
     HIPCK(h, hipEventRecord(t->bucket_ev[3], st));          // Conv4Channel (linears, biases, PReLU slopes)
     // ---- M_space: feat_space = X_flat @ M_space ------------------------------------------------
-    HIPCK(h, launch_space_apply_bwd(t->dBufM, 1024, 0, c.X, t->dms, imgs, st));
-    if (og.M_space) HIPCK(h, launch_mspace_grad_in(og.M_space, t->dms, imgs, st));
-    HIPCK(h, launch_sigmoid_bwd(t->dms, 64, c.ms, 64, rows, 64, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_space_apply_bwd(t->dBufM, 1024, 0, c.X, t->dms, imgs, st));
+    if (og.M_space) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_mspace_grad_in(og.M_space, t->dms, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_sigmoid_bwd(t->dms, 64, c.ms, 64, rows, 64, st));
     // ---- Conv4Space ------------------------------------------------------------------------------
     RC(LB(t->sp[8], c.sp[8], t->dms, 64, 0, t->d256a, 64, 64, nullptr, 0, 0));
     RC(LB(t->sp[7], c.sp[7], t->d256a, 64, 0, t->d256b, 64, 64, t->dms, 64, 0));
@@ -631,19 +642,19 @@ int train_losses(ffr_handle* h, TrainState* t, Ctx& c, const Work& w, const floa
     k.w_ce_ocl = (float)(lw[3] / N);
     // ss_channel term on feat_channel (bufM[:, 512:1024]): Gram, difference to the target (ss_channel of the clean
     // feature map = the first 512 columns of channelF_cat), gradient back through the Gram and the normalisation
-    HIPCK(h, launch_loss_ch_prep(c.bufM, 1536, 512, t->lYht, t->lYh, t->rowdot, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_loss_ch_prep(c.bufM, 1536, 512, t->lYht, t->lYh, t->rowdot, imgs, st));
     RC(gemm_batched(h, w, t->lYht, 512 * 64, 64, t->lYht, 512 * 64, 512, t->dMc, 512, (long long)512 * 512, 512, imgs, st));
     int n_ssc = 0;
-    HIPCK(h, launch_ssc_loss_grad(t->dMc, c.cat, imgs, N, k.w_ss_channel, t->p_ssc, &n_ssc, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_ssc_loss_grad(t->dMc, c.cat, imgs, N, k.w_ss_channel, t->p_ssc, &n_ssc, st));
     RC(gemm_batched(h, w, t->dMc, (long long)512 * 512, 512, t->lYh, 64 * 512, 64, t->dRawt, 64, 512 * 64, 512, imgs, st));
-    HIPCK(h, launch_loss_ch_finish(t->dRawt, t->lYht, t->rowdot, t->extM, 1024, 512, imgs, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_loss_ch_finish(t->dRawt, t->lYht, t->rowdot, t->extM, 1024, 512, imgs, st));
     // ss_space term on feat_space (bufM[:, 0:512])
-    HIPCK(h, launch_ss_space_loss(c.bufM, 1536, 0, c.bufS, imgs, N, k.w_ss_space, t->p_sss, t->extM, 1024, 0, st));
-    HIPCK(h, launch_vec_losses(c.fnew, f_enc, N, 2.0f * k.w_identity, k.w_triplet, 0.1f, t->df_ext, t->p_vec, st));
-    HIPCK(h, launch_ce_loss(c.cosv, CLS_PAD, c.label, N, N_CLASSES, COSFACE_S, COSFACE_M, k.w_ce_non, k.w_ce_ocl, t->dcos,
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_ss_space_loss(c.bufM, 1536, 0, c.bufS, imgs, N, k.w_ss_space, t->p_sss, t->extM, 1024, 0, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_vec_losses(c.fnew, f_enc, N, 2.0f * k.w_identity, k.w_triplet, 0.1f, t->df_ext, t->p_vec, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_ce_loss(c.cosv, CLS_PAD, c.label, N, N_CLASSES, COSFACE_S, COSFACE_M, k.w_ce_non, k.w_ce_ocl, t->dcos,
                             t->p_ce, t->hit, st));
     LossParts lp{t->p_sss, t->p_ssc, t->p_vec, t->p_ce, t->hit, n_ssc};
-    HIPCK(h, launch_loss_finish(lp, N, k, t->loss_out, st));
+    TLAUNCH(FFR_KC_TRAIN_LOSS, launch_loss_finish(lp, N, k, t->loss_out, st));
     t->loss_grads_ready = true;
     return FFR_OK;
 }
@@ -886,7 +897,7 @@ int ffr_train_set(ffr_handle* h, int which, const char* key, const float* host_i
 int ffr_train_zero_grad(ffr_handle* h, void* stream) {
     TrainState* t;
     FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
-    HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, (hipStream_t)stream));
+    { hipStream_t st = (hipStream_t)stream; Scope _ps(h, st, FFR_KC_TRAIN_OPTIM, 0.0, 4.0 * t->n_flat); HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, st)); }
     return FFR_OK;
 }
 
@@ -905,16 +916,16 @@ int ffr_train_forward(ffr_handle* h, int slot, const float* featmap_nchw, const 
     RC(ensure_scratch(h, t, imgs));
     Ctx& c = t->ctx[slot];
     RC(ensure_ctx(h, t, c, G, N));
-    HIPCK(h, launch_nchw_to_nhwc(featmap_nchw, c.X, 512, imgs, 49, 512, st));
+    TLAUNCH(FFR_KC_TRAIN_ELEM, launch_nchw_to_nhwc(featmap_nchw, c.X, 512, imgs, 49, 512, st));
     if (label) HIPCK(h, hipMemcpyAsync(c.label, label, (size_t)imgs * 4, hipMemcpyDeviceToDevice, st));
     RC(train_forward(h, t, c, w, st));
     if (f_new) HIPCK(h, hipMemcpyAsync(f_new, c.fnew, (size_t)imgs * 512 * 4, hipMemcpyDeviceToDevice, st));
     if (pred_loss || pred_label)
-        HIPCK(h, launch_cosface_out(c.cosv, CLS_PAD, c.label, pred_loss, pred_label, imgs, N_CLASSES, COSFACE_S, COSFACE_M, st));
-    if (M_space) HIPCK(h, launch_mspace_out(c.ms, M_space, imgs, st));
+        TLAUNCH(FFR_KC_TRAIN_LOSS, launch_cosface_out(c.cosv, CLS_PAD, c.label, pred_loss, pred_label, imgs, N_CLASSES, COSFACE_S, COSFACE_M, st));
+    if (M_space) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_mspace_out(c.ms, M_space, imgs, st));
     if (M_channel) HIPCK(h, hipMemcpyAsync(M_channel, c.Mc, (size_t)imgs * 512 * 512 * 4, hipMemcpyDeviceToDevice, st));
-    if (feat_space) HIPCK(h, launch_nhwc_to_nchw(c.bufM, 1536, feat_space, imgs, 49, 512, st));
-    if (feat_channel) HIPCK(h, launch_nhwc_to_nchw(c.bufM + 512, 1536, feat_channel, imgs, 49, 512, st));
+    if (feat_space) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_nhwc_to_nchw(c.bufM, 1536, feat_space, imgs, 49, 512, st));
+    if (feat_channel) TLAUNCH(FFR_KC_TRAIN_ELEM, launch_nhwc_to_nchw(c.bufM + 512, 1536, feat_channel, imgs, 49, 512, st));
     return FFR_OK;
 }
 
@@ -941,7 +952,8 @@ int ffr_train_adam_step(ffr_handle* h, double lr, double beta1, double beta2, do
     TrainState* t;
     FFR_DEVICE_SCOPE(h); RC(get_train(h, &t));
     t->adam_step += 1;
-    HIPCK(h, launch_adam(t->P, t->Gr, t->M1, t->M2, t->n_flat, lr, beta1, beta2, eps, weight_decay,
+    hipStream_t st = (hipStream_t)stream;
+    TLAUNCH(FFR_KC_TRAIN_OPTIM, launch_adam(t->P, t->Gr, t->M1, t->M2, t->n_flat, lr, beta1, beta2, eps, weight_decay,
                          clip_value > 0.0 ? (float)clip_value : 3.0e38f, t->adam_step, (hipStream_t)stream));
     return FFR_OK;
 }
@@ -1092,7 +1104,7 @@ int ffr_train_iteration(ffr_handle* h, const float* img_non, const float* img_oc
     RC(train_forward(h, t, c, w, st));
     RC(train_losses(h, t, c, w, f_enc, loss_weight, st));
     if (out5) HIPCK(h, hipMemcpyAsync(out5, t->loss_out, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, st));
+    { Scope _ps(h, st, FFR_KC_TRAIN_OPTIM, 0.0, 4.0 * t->n_flat); HIPCK(h, hipMemsetAsync(t->Gr, 0, t->n_flat * 4, st)); }
     OutGrads og{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     RC(train_backward(h, t, c, w, og, st, true));
     c.valid = false;

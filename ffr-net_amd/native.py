@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 KCLASS_NAMES = ['conv_igemm', 'stem', 'se', 'combine', 'head', 'selfsim', 'channel',
-                'space', 'layout', 'score', 'wino', 'wino_fused', 'wgrad']
+                'space', 'layout', 'score', 'wino', 'wino_fused', 'wgrad',
+                'train_bn', 'train_loss', 'train_optim', 'train_xform', 'train_elem']
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -26,7 +27,7 @@ class TensorDesc(C.Structure):
 
 class KClassStat(C.Structure):
     _fields_ = [('launches', C.c_int64), ('ms', C.c_double), ('flops', C.c_double),
-                ('bytes', C.c_double), ('flops_executed', C.c_double)]
+                ('bytes', C.c_double), ('flops_executed', C.c_double), ('flops_useful', C.c_double)]
 
 
 class ConvDesc(C.Structure):
@@ -368,7 +369,8 @@ class Engine(object):
         arr = (KClassStat * len(KCLASS_NAMES))()
         self._ck(self.lib.ffr_profile_read(self._h, arr))
         return {KCLASS_NAMES[i]: dict(launches=int(arr[i].launches), ms=arr[i].ms,
-                                      flops=arr[i].flops, bytes=arr[i].bytes, flops_executed=arr[i].flops_executed)
+                                      flops=arr[i].flops, bytes=arr[i].bytes, flops_executed=arr[i].flops_executed,
+                                      flops_useful=arr[i].flops_useful)
                 for i in range(len(KCLASS_NAMES))}
 
     # -- test hooks -----------------------------------------------------------

@@ -142,7 +142,13 @@ enum {
     FFR_KC_WINO_FUSED = 11, /* k_wino_fused: the 36 GEMMs + output transform of a Winograd conv (MFMA-bound; the
                                dominant kernel of the forward) */
     FFR_KC_WGRAD = 12,      /* k_wgrad: weight gradients of the training step as TN GEMMs (MFMA-bound) */
-    FFR_KC_COUNT = 13
+    /* the HBM-bound kernels of the training step (include/ffrnet_train.h), itemised so that the classes sum to the step */
+    FFR_KC_TRAIN_BN = 13,     /* train-mode BatchNorm: statistics, apply (+PReLU/residual), backward                  */
+    FFR_KC_TRAIN_LOSS = 14,   /* the four loss items and their cotangents, CosFace head kernels                        */
+    FFR_KC_TRAIN_OPTIM = 15,  /* clip_grad_value_ + Adam over the flat buffers                                         */
+    FFR_KC_TRAIN_XFORM = 16,  /* Winograd weight / gradient transforms, dgrad packing, reflection folds, transposes    */
+    FFR_KC_TRAIN_ELEM = 17,   /* the remaining elementwise / layout kernels of RecNet's train forward and backward     */
+    FFR_KC_COUNT = 18
 };
 typedef struct {
     int64_t launches;
@@ -151,6 +157,10 @@ typedef struct {
     double  bytes;
     double  flops_executed; /* what the matrix cores really did (Winograd F(4x4,3x3) launches
                                execute 36/144 of the direct MACs, plus tile padding)       */
+    double  flops_useful;   /* flops_executed without padding: the multiplies the algorithm the launch runs NEEDS --
+                               direct convolution / GEMM: = flops; Winograd F(4x4,3x3): flops / 4 (36 instead of 144
+                               multiplies per 4x4 output tile; tiles hanging over 14x14 / 7x7 maps, rows beyond T
+                               and zero-padded channels are executed but not useful)       */
 } ffr_kclass_stat;
 int ffr_profile_enable(ffr_handle* h, int on);
 /* Experiment knobs of one handle.  The library reads NO environment variable: every kernel-selection

@@ -687,6 +687,16 @@ def test_bench_and_trainer_two_ranks_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['config']['global_batch'] == 32 and d['steps'] == 2
+    # the training workload with its roofline block ON: the profiled iterations contain the gradient all-reduce, so every
+    # rank must run them (rank 0 alone would wait in the collective for ever)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'train', '--steps', '1', '--warmup', '1',
+           '--batch', '8', '--no-cpu-baseline']
+    out = _Sub.run(cmd, env=dict(env, FFR_BENCH_LIVE_PMC='0'), cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['roofline']['frac'] > 0
+    pc = d['roofline']['per_class']
+    assert {'train_bn', 'train_loss', 'train_optim', 'wgrad', 'wino_fused'} <= set(pc), sorted(pc)
     out = _Sub.run([sys.executable, os.path.join(root, 'tools', 'ddp_two_ranks_one_gpu.py')], cwd=root, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
@@ -706,6 +716,26 @@ def test_rccl_one_rank_runs_the_product_collectives():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], cwd=root, env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'OK' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+def test_bench_line_carries_the_three_roofline_fractions():
+    """frac (executed), frac_useful (padding-free), frac_algorithmic_survey_8d, numeric `traffic` (or
+    null) and the traffic ratio are top-level scalars of `roofline`; a small batch keeps this quick."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFR_BENCH_LIVE_PMC='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--batch', '128', '--steps', '3', '--warmup', '2',
+                          '--no-cpu-baseline', '--no-secondary'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])['roofline']
+    assert 0 < r['frac_useful'] < r['frac'] < 1.0
+    assert r['frac_algorithmic_survey_8d'] > r['frac']            # Winograd executes a quarter of the direct multiplies
+    assert 'traffic' in r and (r['traffic'] is None or r['traffic'] > 0)
+    assert 'traffic_ratio_vs_compulsory' in r and r['gflop_useful_per_launch'] < r['gflop_executed_per_launch']
+    assert 0 < r['per_bound']['whole_step']['frac_useful'] < r['per_bound']['whole_step']['frac_of_mfma_peak']
 
 
 def test_options_api(engine):

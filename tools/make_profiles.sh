@@ -17,6 +17,12 @@ if bash tools/pmc_bench.sh > "$O/pmc_bench.log" 2>&1 && grep -q "\"so_sha256\": 
 else
   echo "PMC pass failed or measured another build: profiles/${RD}_pmc_hbm_traffic.json NOT updated" | tee "$O/pmc_FAILED.txt"
 fi
+if FFR_PMC_WORKLOAD=train bash tools/pmc_bench.sh > "$O/pmc_train.log" 2>&1 && grep -q "\"so_sha256\": \"$SHA\"" "$R/gpurun_out/pmc_bench/summary.json"; then
+  cp -- "$R/gpurun_out/pmc_bench/summary.json" "$O/${RD}_pmc_train_traffic.json"
+  cp -- "$O/${RD}_pmc_train_traffic.json" "$R/profiles/${RD}_pmc_train_traffic.json"
+else
+  echo "training PMC pass failed or measured another build: profiles/${RD}_pmc_train_traffic.json NOT updated" | tee "$O/pmc_train_FAILED.txt"
+fi
 python3 bench.py > "$O/${RD}_bench.json" 2> "$O/bench.err" || echo "bench rc $?"
 for b in 128 64; do
   python3 bench.py --batch $b --no-cpu-baseline --no-secondary > "$O/${RD}_bench_batch$b.json" 2>> "$O/bench.err" || echo "bench$b rc $?"
@@ -34,6 +40,7 @@ for b in 256 128 64; do
   python3 "$R/tools/layer_times.py" "$O/prof$b/p_kernel_trace.csv" > "$O/${RD}_bench_batch${b}_layer_times.txt" || true
   rm -rf -- "$O/prof$b"
 done
+python3 "$R/tools/roofline_check.py" "$O/${RD}_bench_batch256_kernel_stats.csv" "$O/${RD}_bench.json" > "$O/${RD}_roofline_check.txt" 2>&1 || echo "roofline_check: DISAGREEMENT (see ${RD}_roofline_check.txt)"
 rocprofv3 --kernel-trace --stats -d "$O/proft" -o p --output-format csv -- python3 "$R/bench.py" --workload train --steps 5 --warmup 2 --no-roofline > "$O/${RD}_train_step_under_rocprof.json" 2>/dev/null || true
 cp -- "$O/proft/p_kernel_stats.csv" "$O/${RD}_train_step_kernel_stats.csv" || true
 rm -rf -- "$O/proft"

@@ -9,16 +9,18 @@ OUT="$R/gpurun_out/pmc_bench"
 rm -rf -- "$OUT"; mkdir -p -- "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export FFR_BENCH_LIVE_PMC=0      # the profiled bench never starts profiler passes of its own
-B="${FFR_PMC_BATCH:-256}"
+WL="${FFR_PMC_WORKLOAD:-embed}"      # embed (bench.py's headline workload) | train (bench.py --workload train: one k_stem launch per iteration)
+if [ "$WL" = train ]; then B="${FFR_PMC_BATCH:-128}"; else B="${FFR_PMC_BATCH:-256}"; fi
 PT="${FFR_PMC_PASS_TIMEOUT:-200}"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   d=$(echo $c | cut -d' ' -f1)
-  timeout "$PT" rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" -- python3 "$R/bench.py" --batch "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>"$OUT/$d.err"
+  timeout "$PT" rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$d" -- python3 "$R/bench.py" --workload "$WL" --batch "$B" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > /dev/null 2>"$OUT/$d.err"
 done
 python3 - <<PY
 import csv, glob, collections, json, hashlib
 R = '$R'
 BATCH = int('$B')
+WL = '$WL'
 sha = hashlib.sha256(open(R + '/ffr-net_amd/libffrnet_hip.so', 'rb').read()).hexdigest()
 STEPS = 3          # warmup 1 + steps 2 forwards at batch BATCH; the batch-8 parity forward in front of them is cut off
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -35,7 +37,7 @@ for f in glob.glob('$OUT/*/*/*counter_collection.csv'):
             continue
         tot[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[k][r['Counter_Name']] += 1
-out = {'so_sha256': sha, 'batch': BATCH, 'how': 'tools/pmc_bench.sh: rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 --warmup 1: the 3 '
+out = {'so_sha256': sha, 'batch': BATCH, 'workload': WL, 'how': 'tools/pmc_bench.sh: rocprofv3 --pmc, one pass per counter group, bench.py --steps 2 --warmup 1: the 3 '
        'forwards at batch %d (the batch-8 parity forward is excluded); FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact. '
        'FETCH_SIZE counts L2 misses, Infinity-Cache hits included (MI355X_MICROARCH.md): re-reads of a 151 MB V by the other XCDs '
        'appear here although they need not reach HBM.' % BATCH, 'kernels': {}}

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Recompute bench.py's roofline block for the dominant kernel from the committed rocprofv3 summary and a layer table.
+    python tools/roofline_check.py profiles/r04_bench_batch256_kernel_stats.csv profiles/r04_bench.json [--tol 0.03]
+Independent of the library: executed / useful FLOPs come from the layer shapes below (batch from the bench line),
+the average launch time from the rocprofv3 --kernel-trace --stats CSV.  Exits non-zero when a figure of the bench
+line disagrees by more than --tol.  (The bench line and the CSV are two runs of the same command on the same build.)"""
+import csv
+import json
+import math
+import sys
+
+PEAK = 157.3e12
+GFLOP_PER_IMAGE = 15.1427
+
+
+def fused_layers():
+    """(H, cin, cout) of every convolution k_wino_fused runs at batch >= 128: the 3x3 / stride-1 convolutions of the
+    trunk (model_ir_se50.py:66-69: conv1 of 24 units at the unit's input size, conv2 of the 20 stride-1 units) and of
+    RecNet: Conv4Space's first three, ChannelFlipMerge and Conv4Merge (recnet.py:362-394)."""
+    out, h, cin = [], 112, 64
+    for depth, n in ((64, 3), (128, 4), (256, 14), (512, 3)):
+        for u in range(n):
+            out.append((h, cin, depth))                  # conv1: stride 1 at the input resolution
+            if u == 0:
+                h //= 2                                  # conv2 of a stage's first unit has stride 2: direct kernel
+            else:
+                out.append((h, depth, depth))
+            cin = depth
+    out += [(7, 561, 256), (7, 256, 256), (7, 256, 256)]
+    out += [(7, 1024, 512), (7, 512, 512), (7, 512, 512), (7, 1536, 512), (7, 512, 512), (7, 512, 512)]
+    return out
+
+
+def pad(v, m):
+    return (v + m - 1) // m * m
+
+
+def main():
+    tol = float(sys.argv[sys.argv.index('--tol') + 1]) if '--tol' in sys.argv else 0.03
+    stats, bench = sys.argv[1], sys.argv[2]
+    line = [l for l in open(bench) if l.startswith('{')][-1]
+    b = json.loads(line)
+    r = b['roofline']
+    n = b['config']['batch_per_gpu']
+    calls = ns = 0
+    for row in csv.DictReader(open(stats)):
+        if 'k_wino_fused' in row['Name']:
+            calls += int(row['Calls'])
+            ns += int(row['TotalDurationNs'])
+    avg_us = ns / calls / 1e3
+    L = fused_layers()
+    ex = us = 0.0
+    for h, cin, cout in L:
+        t = n * math.ceil(h / 4) ** 2
+        ex += 2 * 36 * pad(t, 32) * pad(cin, 32) * pad(cout, 64)
+        us += 2 * n * h * h * 9 * cin * cout / 4
+    nl = len(L)
+    mine = {'launches_per_step': nl, 'avg_launch_us': avg_us,
+            'gflop_executed_per_launch': ex / nl / 1e9, 'gflop_useful_per_launch': us / nl / 1e9,
+            'frac': ex / nl / (avg_us * 1e-6) / PEAK, 'frac_useful': us / nl / (avg_us * 1e-6) / PEAK,
+            'frac_algorithmic_survey_8d': b['value'] / b['n_gpus'] * GFLOP_PER_IMAGE * 1e9 / PEAK}
+    bad = 0
+    print('%-30s %12s %12s %8s' % ('figure', 'recomputed', 'bench line', 'diff'))
+    for k, v in mine.items():
+        got = r.get(k)
+        d = abs(got - v) / abs(v) if got is not None else float('inf')
+        flag = '' if d <= tol else '   <-- DISAGREES'
+        bad += d > tol
+        print('%-30s %12.4f %12s %7.2f%%%s' % (k, v, got, d * 100, flag))
+    print('k_wino_fused: %d calls in %s = %d forwards of %d launches' % (calls, stats, calls // nl, nl))
+    if calls % nl:
+        print('   <-- call count is not a multiple of %d launches per step' % nl)
+        bad += 1
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
