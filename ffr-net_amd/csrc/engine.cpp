@@ -105,6 +105,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     RC(upload(h, owner, bias, &L->bias));
     L->wu = nullptr;
     L->wuc = nullptr;
+    L->wuq = nullptr;
     const int wino_min_cin = h->opt.wino_mincin;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
         // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
@@ -142,6 +143,23 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
                             for (int e = 0; e < 4; ++e) dst[e] = src[e];
                         }
         RC(upload(h, owner, wuc, &L->wuc));
+        // ... and in the order k_wino_fused_q streams them (wino_fused_q.hip): per 64-channel group and 16-channel K slice
+        // (dq), per xi, one 1 KB fragment per wave: lane = 16 * (k group) + (output channel & 15) of the wave's 16 channels,
+        // the lane's four floats = k 16 dq + 4 (k group) + 0..3
+        if (L->cin_pad <= h->opt.wf_phased_maxk && L->cin_pad % 32 == 0) {
+            const int ndq = L->cin_pad / 16;
+            std::vector<float> wuq(wu.size());
+            for (int nb = 0; nb < nbn; ++nb)
+                for (int dq = 0; dq < ndq; ++dq)
+                    for (int xi = 0; xi < 36; ++xi)
+                        for (int wv = 0; wv < 4; ++wv)
+                            for (int ln = 0; ln < 64; ++ln) {
+                                float* dst = &wuq[(((((size_t)nb * ndq + dq) * 36 + xi) * 4 + wv) * 64 + ln) * 4];
+                                const float* src = &wu[((size_t)xi * L->cout_pad + nb * 64 + 16 * wv + (ln & 15)) * L->cin_pad + 16 * dq + 4 * (ln >> 4)];
+                                for (int e = 0; e < 4; ++e) dst[e] = src[e];
+                            }
+            RC(upload(h, owner, wuq, &L->wuq));
+        }
     }
     L->slope = nullptr;
     if (slope) {
@@ -279,7 +297,9 @@ void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, i
 // plan + launch one (possibly batched) implicit-GEMM described by `a` (M, nkt, cout_pad, nbatch set)
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse) {
     int tile, nblocks;
-    plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, c.tile, h->opt.sk_minunits, &tile, &nblocks, &a.granule);
+    int force = c.tile;
+    if (!force && a.cout_pad == 64 && a.nbatch == 1 && a.M >= 65536 && a.nkt >= 9) force = h->opt.igemm_tile64;   // A/B knob
+    plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, force, h->opt.sk_minunits, &tile, &nblocks, &a.granule);
     int bm, bn;
     igemm_tile_shape(tile, &bm, &bn);
     a.mtiles = (a.M + bm - 1) / bm;
@@ -431,7 +451,10 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nb * 40 * sizeof(unsigned long long)));
                 HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nb * 40 * sizeof(unsigned long long), st));
                 f.trace = dbuf;
-                HIPCK(h, launch_wino_fused(f, st));
+                f.Uq = (phased && h->opt.wf_q) ? L.wuq : nullptr;
+                const bool qform = wino_fused_q_ok(f);
+                if (qform) HIPCK(h, launch_wino_fused_q(f, st));
+                else HIPCK(h, launch_wino_fused(f, st));
                 HIPCK(h, hipStreamSynchronize(st));
                 std::vector<unsigned long long> tr((size_t)nb * 40);
                 HIPCK(h, hipMemcpy(tr.data(), dbuf, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -449,11 +472,14 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 }
                 if (phased) {    // the kernel reports per phase: input transform, wait at the barrier behind it
                     const int cpp = 4, nph = f.nkc / cpp;                      // K chunks per phase, phases
-                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel, %d-channel blocks): %d live blocks of %d | per block (wave 0): "
+                    fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel, %d-channel blocks%s): %d live blocks of %d | per block (wave 0): "
                                     "prologue %.0f loop %.0f = %d phases x (transform %.0f + barrier %.0f + %d K chunks of %.0f) epilogue %.0f cyc | "
-                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, half_n ? 32 : 64, cnt, nb,
+                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, half_n ? 32 : 64, qform ? ", q form: all xi per wave" : "", cnt, nb,
                             pro / cnt, loop / cnt, nph, ep[0] / cnt, ep[1] / cnt, cpp, (loop / cnt / nph - ep[0] / cnt - ep[1] / cnt) / cpp, epi / cnt,
                             (double)(r1 - r0) / 100.0);
+                    if (qform) fprintf(stderr, "[wf trace]    q-form epilogue: tiles 0-15 (register transform + activation + to LDS) %.0f, barrier + tiles 16-31 with the stores of "
+                                               "tiles 0-15 underneath %.0f, barrier + stores of tiles 16-31 %.0f cyc\n",
+                                       ep[2] / cnt, ep[3] / cnt, (epi - ep[2] - ep[3]) / cnt);
                 }
                 else
                     fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
@@ -465,7 +491,9 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             }
 #endif
             Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec, flops / 4.0);
-            HIPCK(h, launch_wino_fused(f, st));
+            f.Uq = (phased && h->opt.wf_q) ? L.wuq : nullptr;
+            if (wino_fused_q_ok(f)) HIPCK(h, launch_wino_fused_q(f, st));
+            else HIPCK(h, launch_wino_fused(f, st));
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
             return FFR_OK;
         }
@@ -858,6 +886,7 @@ int ffr_create(ffr_handle** out, int device) {
     hipError_t e = igemm_init();
     if (e == hipSuccess) e = gemm_stream_init();
     if (e == hipSuccess) e = wino_fused_init();
+    if (e == hipSuccess) e = wino_fused_q_init();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
@@ -1195,6 +1224,7 @@ const OptEntry OPTIONS[] = {
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
     {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
     {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1},
+    {"wf_q", &Options::wf_q, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {

@@ -82,6 +82,7 @@ hipError_t launch_wino_in_chunked(const float* x, float* Vc, int N, int H, int W
                                   hipStream_t stream);
 struct WinoFusedArgs {
     const float* Vc; const float* Uc;       // Vc == null: the kernel transforms x itself (phased mode)
+    const float* Uq;                        // phased mode: the weights in the per-wave order of k_wino_fused_q, or null
     const float* x;                         // phased mode: input [N,H,W,in_pitch] ...
     unsigned x_bytes;                       // ... and its size in bytes (<= 1 GiB; out-of-range reads return zeros)
     int in_pitch, pad_mode;
@@ -100,6 +101,11 @@ hipError_t launch_combine_in_c(const float* res, const float* scale, const float
 int wino_fused_blocks(const WinoFusedArgs& a);
 hipError_t wino_fused_init();
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream);
+// wino_fused_q.hip: the phased launch in the form where a wave owns all 36 xi of 32 tiles x 16 channels (16x16x4 MFMAs,
+// output transform in registers)
+hipError_t wino_fused_q_init();
+bool wino_fused_q_ok(const WinoFusedArgs& a);
+hipError_t launch_wino_fused_q(WinoFusedArgs a, hipStream_t stream);
 inline size_t wino_chunked_floats(long long T, int cin_pad) { return (size_t)((T + 31) / 32) * 32 * 36 * cin_pad; }
 
 // ---- measurement: what the fp32 matrix cores deliver on THIS device (probe.hip) ------------------------

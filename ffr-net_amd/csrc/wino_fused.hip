@@ -22,65 +22,9 @@
 // loop does not use); a thread then owns (tile, 4 channels), applies A^T m A and the convolution epilogue and stores 16
 // bytes per pixel; a wave-store covers 8 tiles x 128 bytes.  DESIGN.md 3.2 has the measurements behind each choice.
 #include "ffr_kernels.h"
+#include "wino_math.h"
 
 namespace ffr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-
-// v = B^T d for any vector width, 12 operations (shared sub-expressions of the F(4x4,3x3) input transform)
-template <typename V>
-__device__ __forceinline__ void bt6t(const V d[6], V v[6]) {
-    const V p = d[4] - 4.f * d[2], q = d[3] - 4.f * d[1];
-    const V t0 = d[4] - d[2], t1 = d[3] - d[1];
-    v[0] = 4.f * d[0] + (d[4] - 5.f * d[2]);
-    v[1] = p + q;
-    v[2] = p - q;
-    v[3] = t0 + 2.f * t1;
-    v[4] = t0 - 2.f * t1;
-    v[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
-}
-
-// v = B^T d (vector form, as in winograd.hip)
-__device__ __forceinline__ void bt6v(const f32x4 d[6], f32x4 v[6]) {
-    v[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-    v[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-    v[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-    v[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
-    v[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
-    v[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-}
-
-// y = A^T m on a channel pair (packed fp32)
-__device__ __forceinline__ void at6p(const f32x2 m[6], f32x2 y[4]) {
-    const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-    y[0] = m[0] + s12 + s34;
-    y[1] = d12 + 2.f * d34;
-    y[2] = s12 + 4.f * s34;
-    y[3] = d12 + 8.f * d34 + m[5];
-}
-
-// y = A^T m on four channels
-__device__ __forceinline__ void at6q(const f32x4 m[6], f32x4 y[4]) {
-    const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-    y[0] = m[0] + s12 + s34;
-    y[1] = d12 + 2.f * d34;
-    y[2] = s12 + 4.f * s34;
-    y[3] = d12 + 8.f * d34 + m[5];
-}
-
-// y = A^T m (scalar form)
-__device__ __forceinline__ void at6s(const float m[6], float y[4]) {
-    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-    y[0] = m[0] + s12 + s34;
-    y[1] = d12 + 2.f * d34;
-    y[2] = s12 + 4.f * s34;
-    y[3] = d12 + 8.f * d34 + m[5];
-}
 
 // ---- input transform into the chunked operand order ---------------------------------------------------------
 // grid (mbn, cin_pad / 32); wave w of a block = K chunk 4*blockIdx.y + w of tile group blockIdx.x; lane = piece
@@ -325,10 +269,21 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     }
 
     // operand streams of this wave: one 16-byte fragment per lane, xi and K chunk (lane-linear in memory)
-    const float* vp = PHASED ? nullptr : a.Vc + ((size_t)mb * nkc * 36 + 9 * wave) * 256 + lane * 4;
+    // Both streams are read through buffer resources: the per-lane part of the address (lane * 16 bytes) sits in one VGPR,
+    // everything else -- tile group, wave, xi, K chunk -- in the SCALAR offset, which SALU instructions and immediates
+    // advance.  (Per-lane 64-bit pointers cost 16 v_add_co / v_addc pairs per K chunk, and every VALU instruction delays
+    // the next MFMA by its issue time: round 4, measured on k_wino_fused_q first.)
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(PHASED ? a.Uc : a.Vc), 0,
+                                                                         PHASED ? 0u : (unsigned)((size_t)a.mbn * nkc * 36 * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)a.Uc, 0, (unsigned)((size_t)a.cout_pad * nkc * 8 * 36 * 4), 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned vp = (unsigned)(mb * nkc * 36 + 9 * wave) * 1024u;                 // scalar byte offsets of this wave's xi 0 in the current K chunk
     // U is packed per 64-channel group: [cout_pad/64][K chunk][xi][2 halves][64 lanes][4]
-    const float* up = NT == 2 ? a.Uc + ((size_t)nb * nkc * 36 + 9 * wave) * 512 + lane * 4
-                              : a.Uc + ((size_t)(nb >> 1) * nkc * 36 + 9 * wave) * 512 + (nb & 1) * 256 + lane * 4;
+    unsigned up = NT == 2 ? (unsigned)(nb * nkc * 36 + 9 * wave) * 2048u
+                          : (unsigned)((nb >> 1) * nkc * 36 + 9 * wave) * 2048u + (unsigned)(nb & 1) * 1024u;
+    auto ldfrag = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned so) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, so, 0));
+    };
     const int rowl = lane & 31;
 
     // 18 accumulator tiles = 288 registers, but a wave addresses 256 AGPRs + 256 VGPRs and hipcc keeps every builtin
@@ -349,15 +304,16 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     if constexpr (MODE == 0) {
     // fragment registers: slot j holds (V, U lo, U hi) of xi j for the K chunk that consumes it next
     f32x4 fv[9], fu[9][NT];
-    auto load = [&](int j, int part, const float* v, const float* u) {
-        if (part == 0) fv[j] = *reinterpret_cast<const f32x4*>(v + j * 256);
-        else fu[j][part - 1] = *reinterpret_cast<const f32x4*>(u + j * 512 + (part - 1) * 256);
+    auto load = [&](int j, int part, unsigned v, unsigned u) {
+        if (part == 0) fv[j] = ldfrag(vrs, v + j * 1024u);
+        else fu[j][part - 1] = ldfrag(urs, u + j * 2048u + (part - 1) * 1024u);
     };
     // ---- prologue: xi 0..7 of K chunk 0 in flight (xi 8 follows in step 0) ----
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
         for (int part = 0; part <= NT; ++part) load(j, part, vp, up);
+        FFR_PIN;            // in THIS order: vmcnt counts loads in issue order, and the loop's waits are derived from it
     }
     FFR_PIN;
     if (FFR_TRACE_ON(a.trace)) st1 = __builtin_amdgcn_s_memtime();
@@ -380,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
                     for (int part = 0; part <= NT; ++part) {
                         if (j == 0) load(8, part, vp, up);                                     // xi 8 of this chunk
-                        else if (!LAST) load(j - 1, part, vp + 36 * 256, up + 36 * 512);       // xi j-1 of the next chunk
+                        else if (!LAST) load(j - 1, part, vp + 36 * 1024u, up + 36 * 2048u);       // xi j-1 of the next chunk
                     }
                 }
                 FFR_PIN;
@@ -390,15 +346,15 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll 1
     for (int kc = 0; kc + 1 < nkc; ++kc) {
         chunk.template operator()<false>();
-        vp += 36 * 256;
-        up += 36 * 512;
+        vp += 36 * 1024u;
+        up += 36 * 2048u;
     }
     chunk.template operator()<true>();
     } else if constexpr (MODE == 1) {
     // ---- PHASED: per 32 input channels: input transform -> LDS, then 4 K chunks with the A fragments from LDS ----
     f32x4 fu[9][NT];
-    auto loadu = [&](int j, int part, const float* u) {
-        fu[j][part] = *reinterpret_cast<const f32x4*>(u + j * 512 + part * 256);
+    auto loadu = [&](int j, int part, unsigned u) {
+        fu[j][part] = ldfrag(urs, u + j * 2048u + part * 1024u);
     };
     f32x4 af[2];
     // LDS image of V: [K chunk c][xi][64 fragments][4]; the fragment of (half h, tile t) sits at position
@@ -522,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
                         for (int part = 0; part < NT; ++part) {
                             if (j == 0) loadu(8, part, up);                                // xi 8 of this chunk
-                            else if (c < 3) loadu(j - 1, part, up + 36 * 512);             // xi j-1 of the next chunk
+                            else if (c < 3) loadu(j - 1, part, up + 36 * 2048u);             // xi j-1 of the next chunk
                         }
                         // last chunk: two patch values of the next phase per step take the place of the weight loads
                         if (c == 3 && j >= 1 && 2 * (j - 1) < NPRE) {
@@ -534,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                     FFR_PIN;
                 }
             }
-            up += 36 * 512;
+            up += 36 * 2048u;
         }
         __syncthreads();                                    // everybody is done reading V before the next transform
     }
