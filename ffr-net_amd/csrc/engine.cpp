@@ -144,17 +144,17 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
                         }
         RC(upload(h, owner, wuc, &L->wuc));
         // ... and in the order k_wino_fused_q streams them (wino_fused_q.hip): per 64-channel group and 16-channel K slice
-        // (dq), per xi, one 1 KB fragment per wave: lane = 16 * (k group) + (output channel & 15) of the wave's 16 channels,
+        // (dq), per xi, one 1 KB fragment per wave (a wave's fragments are contiguous: [nb][wave][dq][xi]): lane = 16 * (k group) + (output channel & 15) of the wave's 16 channels,
         // the lane's four floats = k 16 dq + 4 (k group) + 0..3
         if (L->cin_pad <= h->opt.wf_phased_maxk && L->cin_pad % 32 == 0) {
             const int ndq = L->cin_pad / 16;
             std::vector<float> wuq(wu.size());
             for (int nb = 0; nb < nbn; ++nb)
-                for (int dq = 0; dq < ndq; ++dq)
-                    for (int xi = 0; xi < 36; ++xi)
-                        for (int wv = 0; wv < 4; ++wv)
+                for (int wv = 0; wv < 4; ++wv)
+                    for (int dq = 0; dq < ndq; ++dq)
+                        for (int xi = 0; xi < 36; ++xi)
                             for (int ln = 0; ln < 64; ++ln) {
-                                float* dst = &wuq[(((((size_t)nb * ndq + dq) * 36 + xi) * 4 + wv) * 64 + ln) * 4];
+                                float* dst = &wuq[(((((size_t)nb * 4 + wv) * ndq + dq) * 36 + xi) * 64 + ln) * 4];
                                 const float* src = &wu[((size_t)xi * L->cout_pad + nb * 64 + 16 * wv + (ln & 15)) * L->cin_pad + 16 * dq + 4 * (ln >> 4)];
                                 for (int e = 0; e < 4; ++e) dst[e] = src[e];
                             }

@@ -29,7 +29,7 @@ struct ConvW {
     float* bias = nullptr;
     float* slope = nullptr;
     float* wu = nullptr;     // Winograd F(4,3) weights [36][cout_pad][cin_pad] (G g G^T, BN folded) or null
-    float* wuq = nullptr;    // the same in the per-wave order of k_wino_fused_q ([cout_pad/64][cin_pad/16][36][4 waves][64 lanes][4]) for
+    float* wuq = nullptr;    // the same in the per-wave order of k_wino_fused_q ([cout_pad/64][4 waves][cin_pad/16][36][64 lanes][4]) for
                              // layers that transform their own input (cin_pad <= wf_phased_maxk at load time), or null
     float* wuc = nullptr;    // the same in the K-chunk order k_wino_fused streams ([cout_pad/64][cin_pad/8][36][128][4]) or null
 };
@@ -61,7 +61,7 @@ struct Options {
     int sk_minunits = 18;         // smallest number of K-tiles a stream-K block may own
     int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
     int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
-    int wf_q = 1;                 // 1: the phased fused launches (in-kernel input transform) run k_wino_fused_q when its weights exist
+    int wf_q = 0;                 // 1: the phased fused launches (in-kernel input transform) run k_wino_fused_q (round-4 experiment: a tie)
     int igemm_tile64 = 0;         // > 0: tile shape forced for large direct convolutions with 64 output channels (1..4, ffr_conv_desc.tile)
     int combine_v = 1;            // 1: a bottleneck's combine also writes V for the next conv1 when that runs k_wino_fused from V
     int wf_trace = 0, igemm_trace = 0;   // -DFFR_TRACE builds only: per-launch phase stamps on stderr (synchronises)

@@ -273,11 +273,13 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // everything else -- tile group, wave, xi, K chunk -- in the SCALAR offset, which SALU instructions and immediates
     // advance.  (Per-lane 64-bit pointers cost 16 v_add_co / v_addc pairs per K chunk, and every VALU instruction delays
     // the next MFMA by its issue time: round 4, measured on k_wino_fused_q first.)
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(PHASED ? a.Uc : a.Vc), 0,
-                                                                         PHASED ? 0u : (unsigned)((size_t)a.mbn * nkc * 36 * 1024), 0x00020000);
+    // (V can exceed 4 GB -- 7.4 GB for the 112x112 layer at 1024 images -- so its resource starts at this block's tile group:
+    // 36 KB per K chunk, at most 6.9 MB)
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(PHASED ? a.Uc : a.Vc + (size_t)mb * nkc * 36 * 256), 0,
+                                                                         PHASED ? 0u : (unsigned)nkc * 36u * 1024u, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)a.Uc, 0, (unsigned)((size_t)a.cout_pad * nkc * 8 * 36 * 4), 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
-    unsigned vp = (unsigned)(mb * nkc * 36 + 9 * wave) * 1024u;                 // scalar byte offsets of this wave's xi 0 in the current K chunk
+    unsigned vp = (unsigned)(9 * wave) * 1024u;                                 // scalar byte offsets of this wave's xi 0 in the current K chunk
     // U is packed per 64-channel group: [cout_pad/64][K chunk][xi][2 halves][64 lanes][4]
     unsigned up = NT == 2 ? (unsigned)(nb * nkc * 36 + 9 * wave) * 2048u
                           : (unsigned)((nb >> 1) * nkc * 36 + 9 * wave) * 2048u + (unsigned)(nb & 1) * 1024u;

@@ -64,12 +64,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) 
     // MFMA roles of this lane: A = U[channel 16 wave + jt][k group kg], B = V[k group kg][tile jt + 16 nt];
     // D: lane holds tile jt (+ 16 nt), channels 16 wave + 4 kg + r
     const int jt = lane & 15, kg = lane >> 4;
-    // U of this wave: [nb][dq][xi][wave][64 lanes][4]; one step (dq, xi) = 4096 bytes further.  Read through a buffer
+    // U of this wave: [nb][wave][dq][xi][64 lanes][4]; one step (dq, xi) = 1024 bytes further.  Read through a buffer
     // resource: per-lane offset in a VGPR, the step in the SCALAR offset (SALU / immediates; a per-lane 64-bit pointer cost
     // two VALU additions per step, and every VALU instruction delays the next MFMA by its issue time)
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.Uq, 0, (unsigned)((size_t)a.cout_pad * nkc * 8 * 36 * 4), 0x00020000);
-    const unsigned uvoff = (unsigned)(wave * 256 + lane * 4) * 4u;
-    unsigned up = (unsigned)(nb * (nkc >> 1) * 36) * 4096u;          // scalar byte offset of this phase's step 0
+    const unsigned uvoff = (unsigned)lane * 16u;
+    unsigned up = (unsigned)((nb * 4 + wave) * (nkc >> 1) * 36) * 1024u;     // scalar byte offset of this phase's step 0
     // V image in LDS: fragment (dq, nt, xi) = 64 slots of 16 B; the value of (k group kg, tile j) sits in slot
     // 16 kg + 8 (j >> 3) + ((j + 2 kg + dq) & 7): rotated inside groups of 8 tiles so that the 8 lanes of one tile in the
     // transform (4 k groups x 2 dq, fragments 72 KB apart) write 8 different 16-byte bank columns, and the 8 consecutive
@@ -101,8 +101,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) 
 
 #define FFR_PIN __builtin_amdgcn_sched_barrier(0)
     f32x4 fu[WQ_R];
-    f32x4 fv[3][2];                                        // V fragments of the current step and the two after it
-    auto loadu = [&](int slot, unsigned so) { fu[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, uvoff, so, 0)); };
+    f32x4 fv[4][2];                                        // V fragments of the current pair of steps and of the next
+    // step t of the phase: t & 3 goes into the instruction's immediate offset (12 bits), the rest into the scalar offset (one
+    // s_add per four steps)
+    auto loadu = [&](int slot, unsigned base, int t) {
+        fu[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, uvoff + (unsigned)(t & 3) * 1024u, base + (unsigned)(t & ~3) * 1024u, 0));
+    };
     auto readv = [&](int buf, int d, int xi) {
         fv[buf][0] = *(lds_f32x4*)(size_t)(vb[d][0] + xi * 1024);
         fv[buf][1] = *(lds_f32x4*)(size_t)(vb[d][1] + xi * 1024);
@@ -175,10 +179,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) 
             for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vout + (i * 6 + j) * 256) = v[j];
             // the registers of the finished rows take the weight fragments of this phase's first steps (slots 0..10)
             if (i >= 1) {
-                loadu((i - 1) * 2, up + ((i - 1) * 2) * 4096u);
-                loadu((i - 1) * 2 + 1, up + ((i - 1) * 2 + 1) * 4096u);
+                loadu((i - 1) * 2, up, (i - 1) * 2);
+                loadu((i - 1) * 2 + 1, up, (i - 1) * 2 + 1);
             }
-            if (i == 5) loadu(10, up + 10 * 4096u);
+            if (i == 5) loadu(10, up, 10);
         }
         }
         if (FFR_TRACE_ON(a.trace)) se[0] += __builtin_amdgcn_s_memtime() - tp0;       // diagnostics: transform (before the barrier)
@@ -186,37 +190,48 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) 
         if (FFR_TRACE_ON(a.trace)) se[1] += __builtin_amdgcn_s_memtime() - tp0;       // ... incl. the barrier
         readv(0, 0, 0);
         readv(1, 0, 1);
-        // -- 72 steps (dq, xi) of 8 MFMAs: U fragment of the step from the ring, V fragments of the next step from LDS --
-        // (a fold over an index sequence: a plain 72-iteration loop is not unrolled by hipcc and the accumulators would
-        // be indexed dynamically)
-        auto step = [&]<int t>() {
-            constexpr int xi = t % 36;
-            constexpr int cur = t % 3;
-            const f32x4 av = fu[t % WQ_R], b0 = fv[cur][0], b1 = fv[cur][1];
+        // -- 36 pairs of steps (dq, xi), (dq, xi + 1): 16 MFMAs on FOUR accumulator tiles in turn, so that an MFMA's
+        // accumulator was written four MFMAs earlier (with two tiles in turn hipcc put an s_nop between them and the chunk
+        // took 5.3k cycles for 4.6k of MFMAs); U fragments from the ring, V fragments of the next pair from LDS.
+        // (A fold over an index sequence: a plain loop is not unrolled by hipcc and the accumulators would be indexed
+        // dynamically.)
+        auto pairstep = [&]<int p>() {
+            constexpr int t0 = 2 * p, xi0 = t0 % 36;
+            const f32x4 av0 = fu[t0 % WQ_R], av1 = fu[(t0 + 1) % WQ_R];
+            const f32x4 b00 = fv[t0 % 4][0], b01 = fv[t0 % 4][1], b10 = fv[(t0 + 1) % 4][0], b11 = fv[(t0 + 1) % 4][1];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int s = g >> 1, nt = g & 1;
+            for (int g = 0; g < 16; ++g) {
+                const int s = g >> 2, w1 = (g >> 1) & 1, nt = g & 1;
+                const float av = w1 ? av1[s] : av0[s];
+                const float bv = w1 ? (nt ? b11[s] : b10[s]) : (nt ? b01[s] : b00[s]);
                 // inline asm, accumulating in place: with the builtin hipcc picks the three-address form for the first MFMA of
                 // every step (destination != source accumulator), which needs spare AGPRs that do not exist -- it spilled
                 // accumulators to scratch and reloaded them in the loop behind s_waitcnt vmcnt(0)
-                if constexpr (xi < 32) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[xi][nt]) : "v"(av[s]), "v"(nt ? b1[s] : b0[s]));
-                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[xi - 32][nt]) : "v"(av[s]), "v"(nt ? b1[s] : b0[s]));
-                if (g == 0 && t == 72 - WQ_R) offsets();        // the patch offsets of the next phase: live from here to its loads
-                if (g == 1) {
-                    constexpr int tl = t - 1 + WQ_R;            // the step the slot consumed one step ago serves next
-                    if constexpr (t == 0) loadu(WQ_R - 1, up + (WQ_R - 1) * 4096u);
-                    else if constexpr (tl < 72) loadu((t - 1) % WQ_R, up + tl * 4096u);
-                    else if constexpr (2 * (tl - 72) < NPRE) {  // tail of the phase: the first patch values of the next one
+                if (xi0 + w1 < 32) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[(xi0 + w1) & 31][nt]) : "v"(av), "v"(bv));
+                else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(accv[(xi0 + w1) & 3][nt]) : "v"(av), "v"(bv));
+                if (g == 0 && p == 30) offsets();               // the patch offsets of the next phase: live from here to its loads
+                if (g == 1 || g == 2) {                         // the slots the previous pair consumed serve R steps later
+                    constexpr int base = t0 - 2 + WQ_R;
+                    const int tl = base + (g - 1);
+                    if (p == 0) { if (g == 1) loadu(WQ_R - 1, up, WQ_R - 1); }
+                    else if (tl < 72) loadu(tl % WQ_R, up, tl);
+                    else if (2 * (tl - 72) < NPRE) {            // tail of the phase: the first patch values of the next one
                         pre[2 * (tl - 72)] = load_px(2 * (tl - 72), soff_next);
                         pre[2 * (tl - 72) + 1] = load_px(2 * (tl - 72) + 1, soff_next);
                     }
                 }
-                if (g == 2 && t < 70) readv((t + 2) % 3, (t + 2) / 36, (t + 2) % 36);      // two steps ahead (LDS latency under four waves' reads)
+                if constexpr (t0 + 2 < 72) {                    // the next pair's V fragments, one read per MFMA gap
+                    constexpr int ta = t0 + 2, tb = t0 + 3;
+                    if (g == 4) fv[ta % 4][0] = *(lds_f32x4*)(size_t)(vb[ta / 36][0] + (ta % 36) * 1024);
+                    if (g == 5) fv[ta % 4][1] = *(lds_f32x4*)(size_t)(vb[ta / 36][1] + (ta % 36) * 1024);
+                    if (g == 6) fv[tb % 4][0] = *(lds_f32x4*)(size_t)(vb[tb / 36][0] + (tb % 36) * 1024);
+                    if (g == 7) fv[tb % 4][1] = *(lds_f32x4*)(size_t)(vb[tb / 36][1] + (tb % 36) * 1024);
+                }
                 FFR_PIN;
             }
         };
-        [&]<int... T>(std::integer_sequence<int, T...>) { (step.template operator()<T>(), ...); }(std::make_integer_sequence<int, 72>{});
-        up += 72 * 4096u;
+        [&]<int... P>(std::integer_sequence<int, P...>) { (pairstep.template operator()<P>(), ...); }(std::make_integer_sequence<int, 36>{});
+        up += 72 * 1024u;
         __syncthreads();                                    // everybody is done reading V before the next transform
     }
 #undef FFR_PIN

@@ -176,6 +176,10 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
  *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
  *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
+ *   "wf_q" (0)            1: launches that transform their own input run k_wino_fused_q (a wave owns all 36 xi of a
+ *                         16-channel slice, v_mfma_f32_16x16x4_f32, output transform in registers): the round-4
+ *                         experiment, as fast as k_wino_fused<1, 2> and not faster
+ *   "igemm_tile64" (0)    1..4: tile shape forced for the large direct convolutions with 64 output channels
  *   "combine_v" (1)       1: a bottleneck's combine (res * scale + shortcut) also writes the Winograd transform V of its
  *                         output when the next unit's conv1 runs k_wino_fused from V (stage 3 / 4): k_combine_in_c
  *                         replaces k_combine + k_wino_in_c

@@ -144,16 +144,16 @@ def test_winograd_conv_matches_direct_and_torch(engine, case):
     got_d = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, 0, rd).permute(0, 3, 1, 2).cpu()
     assert rel(got_d, ref) < OP_TOL
     # fused kernel with 32x64 blocks (full launches) / with 32x32 blocks (small launches) / transform kernels + batched GEMM
-    # (cin <= 128, mode 1: once in the form where a wave owns all 36 xi of a 16-channel slice -- k_wino_fused_q, option
-    # wf_q, the default -- and once as k_wino_fused<1, 2>)
-    for use_wino, q in ((1, 1), (1, 0), (3, 1), (2, 1)):
-        if q == 0 and cin > 128:
+    # (cin <= 128, mode 1: once as k_wino_fused<1, 2>, the default, and once in the form where a wave owns all 36 xi of a
+    # 16-channel slice -- k_wino_fused_q, option wf_q)
+    for use_wino, q in ((1, 0), (1, 1), (3, 0), (2, 0)):
+        if q == 1 and cin > 128:
             continue
         engine.set_option('wf_q', q)
         try:
             got_w = engine.op_conv3x3(x.cuda(), w, bias, slope, mode, use_wino, rd).permute(0, 3, 1, 2).cpu()
         finally:
-            engine.set_option('wf_q', 1)
+            engine.set_option('wf_q', 0)
         assert rel(got_w, ref) < 1e-4, (use_wino, q)          # Winograd F(4,3) in fp32: measured ~2e-6
         assert rel(got_w, got_d) < 1e-4, (use_wino, q)
 
@@ -789,7 +789,7 @@ def test_experiment_knobs_keep_parity(tmp_path):
                         ('sepool', {'FFR_OPT_SE_MAXTILES': '0'}), ('unfused', {'FFR_OPT_WINO_FUSED': '0'}),
                         ('phased256', {'FFR_OPT_WF_PHASED_MAXK': '256'}), ('direct', {'FFR_OPT_WINO': '0'}),
                         ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nocombinev', {'FFR_OPT_COMBINE_V': '0'}),
-                        ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'}), ('noq', {'FFR_OPT_WF_Q': '0'}),
+                        ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'}), ('qform', {'FFR_OPT_WF_Q': '1'}),
                         ('tile64', {'FFR_OPT_IGEMM_TILE64': '4'})):
         got = run(name, **knobs)
         for k in ('f_new', 'f'):
