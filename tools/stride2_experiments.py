@@ -53,7 +53,7 @@ for H, C in ((112, 64), (56, 128), (28, 256), (14, 512)):
                   flags=0, tile=tile, splitk=1)
         us = timed(kw)
         best = min(best, us)
-        line.append('tile %d %.0f us (%.1f TF)' % (tile, us, gflop / us * 1e-3))
+        line.append('tile %d %.0f us (%.1f TF)' % (tile, us, gflop / us * 1e3))
     print(' '.join(line), flush=True)
     del x, out
     # (b) polyphase F(4x4, 2x2): 25 xi, K = 4 cin, T = N * ceil(Ho / 4)^2 tiles
@@ -77,6 +77,6 @@ for H, C in ((112, 64), (56, 128), (28, 256), (14, 512)):
     io_us = (2 * v_bytes + 2 * m_bytes) / 5e12 * 1e6
     print('          polyphase F(4x4,2x2) lower bound: 25 GEMMs [%d x %d] * [%d x %d] = %.1f GFLOP executed (%.2f of direct): '
           '%.0f us (tile %d, %.1f TF) + V/M round trips %.2f GB at 5 TB/s = %.0f us  => >= %.0f us vs direct %.0f us'
-          % (T, K, K, C, gexec, gexec / gflop, us, tile, gexec / us * 1e-3, (2 * v_bytes + 2 * m_bytes) / 1e9, io_us,
+          % (T, K, K, C, gexec, gexec / gflop, us, tile, gexec / us * 1e3, (2 * v_bytes + 2 * m_bytes) / 1e9, io_us,
              us + io_us, best), flush=True)
     del xg, og
