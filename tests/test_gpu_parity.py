@@ -549,6 +549,10 @@ def test_lfw_protocol_6000_pairs_matches_reference(engine, g9):
     acc_new, acc, det = ffrnet_amd.lfw.get_avg_accuracy(engine.embed, loader, details=True)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    # the input side (lfw.ShardFeeder): host tensors went through the pinned staging buffers to the ENGINE's device, one
+    # block per pair batch, and nothing but this rank's rows was copied (one rank: all of them, exactly once)
+    st = ffrnet_amd.lfw.last_feed_stats
+    assert st['batches'] == 12 and st['h2d_bytes'] == st['shard_bytes'] == st['full_batch_bytes'] == 2 * 6000 * 3 * 112 * 112 * 4, st
     print('6000-pair protocol incl. host->device copies: %.2f s (%.0f pairs/s); acc_new %.6f acc %.6f'
           % (dt, 6000 / dt, acc_new, acc))
     pn, p = det['pred_new'], det['pred']
