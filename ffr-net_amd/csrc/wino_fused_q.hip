@@ -1,19 +1,22 @@
 // k_wino_fused_q: the Winograd F(4x4,3x3) convolution with in-kernel input transform (cin <= 128; reference convolutions
 // pretrain/model_ir_se50.py:67,69) in the form where a wave owns ALL 36 xi of a 32-tile x 16-channel slice.
+// Round-4 experiment, selected by the option "wf_q", OFF by default: it is as fast as
+// k_wino_fused<1, 2> and not faster (DESIGN.md 3.2 has the phase table); kept as the worked example of the form.
 //
 // k_wino_fused<1, 2> (wino_fused.hip) gives wave w the xi in [9w, 9w + 9) for all 32 tiles x 64 channels: the 36 values of
 // one (tile, channel) end up in four waves, so the output transform A^T m A needs the block-wide E[xi][tile][channel]
-// round trip through LDS (2 x 147 KB written and read, two barrier pairs: 16-18k of a block's 83k cycles at cin 64,
-// profiles/r03_wino_fused_phase_trace.txt).  Here wave w owns channels [16w, 16w + 16) of the block's 64 and every xi:
+// round trip through LDS (2 x 147 KB written and read, two barrier pairs).  Here wave w owns channels [16w, 16w + 16) of
+// the block's 64 and every xi:
 //     per xi two v_mfma_f32_16x16x4_f32 tiles (16 channels x 16 tiles each; A = U, B = V) = 8 accumulator registers,
 //     36 x 8 = the same 288 accumulator registers, the same MFMA rate (1024 MACs per 32 cycles);
 //     lane l holds, for tile (l & 15) + 16 nt, the FOUR CONSECUTIVE channels 16w + 4 (l >> 4) + r of all 36 xi,
-// so A^T m A is register arithmetic on float4s (packed fp32 over channel pairs) and a lane ends up with the 16 output
-// pixels x 4 channels of its tiles.  The results still pass through LDS once -- 16 values per (tile, channel) instead of
-// 36, one barrier -- only to be stored as whole 256-byte pixel lines (16 lanes x 16 B) instead of 16-byte pieces of 16
-// different lines per 16-lane group.
-// Price: V (LDS image) is read by all four waves (4 x the LDS reads of the K loop: 32 B/clk/CU of 128), U per wave is
-// the same amount as before in another order (ConvW::wuq).
+// so A^T m A is register arithmetic (packed fp32 over channel pairs) and a lane ends up with the 16 output pixels x 4
+// channels of its tiles.  The results still pass through LDS once -- 16 values per (tile, channel) instead of 36 -- only
+// to be stored as whole 256-byte pixel lines (16 lanes x 16 B) instead of 16-byte pieces of 16 different lines per 16-lane
+// group; the first tile half is stored under the second half's arithmetic.
+// Price: V (LDS image) is read by all four waves (4 x the LDS reads of the K loop), 288 v_accvgpr_read in the epilogue,
+// and twice the operand instructions per MFMA cycle (the MFMA is half as long); U per wave is the same amount as before
+// in another order (ConvW::wuq).
 #include <utility>
 
 #include "ffr_kernels.h"
@@ -25,7 +28,6 @@ constexpr int WQ_V_FLOATS = 2 * 2 * 36 * 256;                 // V image of one 
 constexpr int WQ_LDS_BYTES = (WQ_V_FLOATS + 9 * 64 + 32 * 8) * 4;
 constexpr int WQ_R = 12;                                      // U fragment ring: a slot is reloaded 11 steps (2.8k cycles) ahead
 
-template <int DUMMY>
 __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) 
             asm volatile("" : "+v"(vb[d][nt]));
         }
 
-    // 72 accumulator tiles of 16x16 = 288 registers: xi 0..31 through the builtin (hipcc keeps them in the 256 AGPRs),
-    // xi 32..35 in VGPRs through inline asm (as k_wino_fused does with its 17th / 18th tile)
+    // 72 accumulator tiles of 16x16 = 288 registers: xi 0..31 in the 256 AGPRs, xi 32..35 in VGPRs (as k_wino_fused does with
+    // its 17th / 18th tile); every MFMA is inline asm with a tied accumulator (see the loop)
     f32x4 acc[32][2], accv[4][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_q(const WinoFusedArgs a) 
 }
 
 hipError_t wino_fused_q_init() {
-    return hipFuncSetAttribute((const void*)k_wino_fused_q<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WQ_LDS_BYTES);
+    return hipFuncSetAttribute((const void*)k_wino_fused_q, hipFuncAttributeMaxDynamicSharedMemorySize, WQ_LDS_BYTES);
 }
 
 // The launch k_wino_fused<1, 2> would serve (a.Vc == null, a.x set), with the weights in the per-wave order a.Uq.
@@ -382,7 +384,7 @@ hipError_t launch_wino_fused_q(WinoFusedArgs a, hipStream_t stream) {
     a.mbn = (int)((a.T + 31) / 32);
     a.nbn = a.cout_pad / 64;
     const dim3 grid((a.mbn + 7) / 8 * 8 * a.nbn);
-    hipLaunchKernelGGL((k_wino_fused_q<0>), grid, dim3(256), WQ_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(k_wino_fused_q, grid, dim3(256), WQ_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
