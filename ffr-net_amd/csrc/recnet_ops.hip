@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) z = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ks], HB[ct][ks], z, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 1.0f / (1.0f + __expf(-z[r]));
+            for (int r = 0; r < 16; ++r) z[r] = __builtin_amdgcn_rcpf(1.0f + __expf(-z[r]));      // v_rcp_f32 (1 ulp): an IEEE division is 10 instructions, 16 x 64 of them per image and wave sit between the MFMAs
             if (dbg_M && n == 0) {      // parity tests only: M_channel[c][c'] of image 0, straight from the accumulator tile
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
