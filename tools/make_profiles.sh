@@ -1,10 +1,10 @@
 #!/bin/bash
-# Measurement artefacts of one round (run via gpurun from the repo root):  bash tools/make_profiles.sh r03
+# Measurement artefacts of one round (run via gpurun from the repo root):  bash tools/make_profiles.sh r04
 # Writes gpurun_out/<round>/<round>_*; the PMC summary is installed under profiles/ ONLY when every counter pass succeeded
 # and its so_sha256 is the hash of the library in the tree.
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the root of the snapshot)}"
-RD="${1:-r03}"
+RD="${1:-r04}"
 R="$GRAFT_REPO_ROOT"
 O="$R/gpurun_out/$RD"
 rm -rf -- "$O"; mkdir -p -- "$O"
