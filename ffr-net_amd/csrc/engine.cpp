@@ -106,6 +106,7 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     L->wu = nullptr;
     L->wuc = nullptr;
     L->wuq = nullptr;
+    for (int tau = 0; tau < 4; ++tau) L->wum[tau] = nullptr;
     const int wino_min_cin = h->opt.wino_mincin;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
         // U[xi = i*6+j][co][ci] = (G g G^T)[i][j], same BN folds as the direct weights
@@ -143,6 +144,40 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
                             for (int e = 0; e < 4; ++e) dst[e] = src[e];
                         }
         RC(upload(h, owner, wuc, &L->wuc));
+        // ... for the tile types (4,3), (3,4), (3,3) of the exact 4+4+3+3 tiling of 14x14 maps (wino_mixed.hip): U = G_r g G_c^T with
+        // the 5-point F(3,3) matrix for a 3-output dimension; xi padded to 32 / 32 / 28 with zeros
+        if (L->cin_pad == 256 && pad_mode == 0 && h->opt.wf_mixed) {
+            static const double G3[5][3] = {{0.5, 0, 0}, {-0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0, 0, 1}};
+            L->wum[0] = L->wuc;
+            for (int tau = 1; tau < 4; ++tau) {
+                const int mr = tau >= 2 ? 3 : 4, mc = (tau & 1) ? 3 : 4, ar = mr + 2, ac = mc + 2;
+                const int xp = wino_mixed_xp(tau);
+                std::vector<float> um((size_t)nbn * nkc * xp * 512, 0.f);
+                for (int co = 0; co < cout; ++co) {
+                    const double g = out_bn ? out_bn->s[co] : 1.0;
+                    const int nb = co / 64, nl = co % 64;
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const float* gk = W + ((size_t)co * cin + ci) * 9;
+                        const double sc = (in_bn ? in_bn->s[ci] : 1.0) * g;
+                        double tmp[6][3];
+                        for (int i = 0; i < ar; ++i)
+                            for (int c = 0; c < 3; ++c) {
+                                const double* gr = mr == 4 ? G[i] : G3[i];
+                                tmp[i][c] = gr[0] * gk[0 * 3 + c] + gr[1] * gk[1 * 3 + c] + gr[2] * gk[2 * 3 + c];
+                            }
+                        const int kc = ci / 8, hf = (ci % 8) / 4, e4 = ci % 4;
+                        const int piece = (nl >> 5) * 64 + hf * 32 + (nl & 31);
+                        for (int i = 0; i < ar; ++i)
+                            for (int j = 0; j < ac; ++j) {
+                                const double* gc = mc == 4 ? G[j] : G3[j];
+                                const double u = tmp[i][0] * gc[0] + tmp[i][1] * gc[1] + tmp[i][2] * gc[2];
+                                um[((((size_t)nb * nkc + kc) * xp + (i * ac + j)) * 128 + piece) * 4 + e4] = (float)(u * sc);
+                            }
+                    }
+                }
+                RC(upload(h, owner, um, &L->wum[tau]));
+            }
+        }
         // ... and in the order k_wino_fused_q streams them (wino_fused_q.hip): per 64-channel group and 16-channel K slice
         // (dq), per xi, one 1 KB fragment per wave (a wave's fragments are contiguous: [nb][wave][dq][xi]): lane = 16 * (k group) + (output channel & 15) of the wave's 16 channels,
         // the lane's four floats = k 16 dq + 4 (k group) + 0..3
@@ -225,11 +260,25 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
     return half_n ? 2 : 1;
 }
 
+// True when the convolution runs on the exact 4+4+3+3 tiling (k_wino_fused_mixed): 14x14 map, zero padding, the three extra
+// weight sets packed, scratch large enough, and every CU gets at least two blocks -- the gain comes from pairing a long block
+// with a short one on a CU; with one block per CU the (4,4) blocks set the time and nothing is won.
+// wino_mode 4 forces it (tests).
+bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
+    if (!L.wum[1] || L.pad_mode != 0 || H != 14 || W != 14 || in_pitch != L.cin_pad) return false;
+    WinoMixedGeom g;
+    if (!wino_mixed_geom(H, W, &g) || wino_mixed_v_floats(g, N, L.cin_pad, nullptr) > wino_cap) return false;
+    if (wino_mode == 4) return true;
+    if (wino_mode >= 0 || !h->opt.wino || !h->opt.wino_fused || !h->opt.wf_mixed) return false;
+    return wino_mixed_blocks(N, H, W, L.cout_pad) >= 2 * h->num_cus;
+}
+
 // True when the Winograd convolution (L on N x H x W) will run k_wino_fused over the WHOLE batch from a V that already
 // lies in winoV in fragment order (run_conv with wino_stage 2 / v_chunked): not the in-kernel transform, no split-off
 // remainder, scratch large enough.  run_conv applies the same tests.
 bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap) {
     if (!L.wu || !L.wuc || !h->opt.wino || L.pad_mode != 0) return false;
+    if (wino_mixed_applies(h, L, N, H, W, in_pitch, wino_cap, -1)) return false;     // that path transforms its own V (for now)
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)N * th * tw;
     const double x_bytes = 4.0 * N * H * W * in_pitch;
@@ -367,6 +416,36 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
     const double flops = 2.0 * M * L.cout * (double)L.R * L.S * L.cin;
     const double bytes = 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)M * L.cout + (double)L.cout * L.R * L.S * L.cin);
     const bool wino_on = h->opt.wino != 0;
+    if (wino_mixed_applies(h, L, c.N, c.H, c.W, c.in_pitch, c.wino_cap, c.wino_mode) && c.winoV && c.tile == 0 &&
+        (c.wino_stage == 0 || (c.wino_stage == 2 && c.v_mixed)) &&
+        ((c.out_pitch | c.out_coff | c.res_pitch | c.cout_store) & 3) == 0) {
+        // exact tiling 4+4+3+3 of a 14x14 map (wino_mixed.hip): one transform launch and one fused launch for all four tile types
+        WinoMixedGeom g;
+        wino_mixed_geom(c.H, c.W, &g);
+        if (c.took_wino) *c.took_wino = true;
+        if (c.wino_stage == 0) {
+            Scope s(h, st, FFR_KC_WINO, 0, 4.0 * ((double)c.N * c.H * c.W * L.cin + (double)wino_mixed_v_floats(g, c.N, L.cin_pad, nullptr)));
+            HIPCK(h, launch_wino_in_mixed(c.x, c.winoV, c.N, c.H, c.W, c.in_pitch, L.cin_pad, st));
+        }
+        WinoMixedArgs f{};
+        f.V[0] = c.winoV;
+        for (int tau = 0; tau < 4; ++tau) f.U[tau] = L.wum[tau];
+        f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out; f.tile_sums = c.tile_sums;
+        f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
+        f.cout_pad = L.cout_pad; f.cout_store = c.cout_store; f.out_pitch = c.out_pitch; f.out_coff = c.out_coff;
+        f.res_pitch = c.res_pitch; f.border_bias = L.border; f.flags = c.flags;
+        double fexec = 0.0, fuse = 0.0;
+        for (int tau = 0; tau < 4; ++tau) {
+            const int nr = tau >= 2 ? g.n3 : g.n4, nc = (tau & 1) ? g.n3 : g.n4;
+            const double Tt = (double)c.N * nr * nc;
+            fexec += 2.0 * wino_mixed_xp(tau) * std::ceil(Tt / 32.0) * 32.0 * L.cout_pad * L.cin_pad;
+            fuse += 2.0 * wino_mixed_x(tau) * Tt * L.cout * L.cin;
+        }
+        Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec, fuse);
+        HIPCK(h, launch_wino_fused_mixed(f, st));
+        if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
+        return FFR_OK;
+    }
     if (L.wu && c.winoV && c.tile == 0 && (c.wino_mode >= 1 || (c.wino_mode < 0 && wino_on))) {
         // Winograd F(4x4,3x3): input transform -> 36 batched GEMMs [T x cin] * [cin x cout] -> output transform
         const int th = (c.H + 3) / 4, tw = (c.W + 3) / 4;
@@ -671,7 +750,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
     float* cur = w.bufA;
     float* nxt = w.bufB;
     int ch = H, cw = W, cc = 64;
-    bool v_ready = false;                 // winoV holds the transform of `cur` in the order k_wino_fused streams
+    bool v_ready = false, v_mixed = false;  // winoV holds the transform of `cur` in the order k_wino_fused (/ k_wino_fused_mixed) streams
     for (int i = 0; i < n_blocks; ++i) {
         const Block& b = h->blocks[i];
         const int ho = ch / b.stride, wo = cw / b.stride;
@@ -689,7 +768,7 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
             (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
             c1.wino_stage = 1; c1.took_wino = &chained;
         }
-        if (v_ready) { c1.wino_stage = 2; c1.v_chunked = true; }
+        if (v_ready) { c1.wino_stage = 2; c1.v_chunked = !v_mixed; c1.v_mixed = v_mixed; }
         RC(run_conv(h, b.c1, c1, st));
         if (chained) {
             Scope s(h, st, FFR_KC_WINO, 0, 4.0 * 72.0 * Tt * b.c1.cout_pad);
@@ -729,8 +808,16 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         }
         // the next unit's conv1 reads this unit's output through its Winograd transform: when that conv runs k_wino_fused
         // from V (cin >= 256: stage 3 and 4), the combine writes V itself and the separate transform pass is skipped
-        v_ready = false;
-        if (h->opt.combine_v && i + 1 < n_blocks && (scp || b.stride == 1) && combine_in_c_supported(ho, wo, b.depth) &&
+        v_ready = false; v_mixed = false;
+        if (h->opt.combine_v && i + 1 < n_blocks && (scp || b.stride == 1) && b.depth % 32 == 0 &&
+            wino_mixed_applies(h, h->blocks[i + 1].c1, N, ho, wo, b.depth, w.wino_cap, -1)) {
+            WinoMixedGeom mg;
+            wino_mixed_geom(ho, wo, &mg);
+            const double e = (double)N * ho * wo * b.depth;
+            Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 4.0 * (3.0 * e + (double)wino_mixed_v_floats(mg, N, b.depth, nullptr)));
+            HIPCK(h, launch_combine_in_mixed(w.res, se_scale, scp ? scp : cur, nxt, w.winoV, N, ho, wo, b.depth, st));
+            v_ready = true; v_mixed = true;
+        } else if (h->opt.combine_v && i + 1 < n_blocks && (scp || b.stride == 1) && combine_in_c_supported(ho, wo, b.depth) &&
             wino_accepts_ready_v(h, h->blocks[i + 1].c1, N, ho, wo, b.depth, w.wino_cap)) {
             const double e = (double)N * ho * wo * b.depth;
             Scope s(h, st, FFR_KC_COMBINE, 2.0 * e, 4.0 * (3.0 * e + 36.0 * N * ((ho + 3) / 4) * ((wo + 3) / 4) * b.depth));
@@ -887,6 +974,7 @@ int ffr_create(ffr_handle** out, int device) {
     if (e == hipSuccess) e = gemm_stream_init();
     if (e == hipSuccess) e = wino_fused_init();
     if (e == hipSuccess) e = wino_fused_q_init();
+    if (e == hipSuccess) e = wino_mixed_init();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
@@ -1224,7 +1312,7 @@ const OptEntry OPTIONS[] = {
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
     {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
     {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1},
-    {"wf_q", &Options::wf_q, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
+    {"wf_q", &Options::wf_q, nullptr, 0, 1}, {"wf_mixed", &Options::wf_mixed, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {

@@ -31,6 +31,8 @@ struct ConvW {
     float* wu = nullptr;     // Winograd F(4,3) weights [36][cout_pad][cin_pad] (G g G^T, BN folded) or null
     float* wuq = nullptr;    // the same in the per-wave order of k_wino_fused_q ([cout_pad/64][4 waves][cin_pad/16][36][64 lanes][4]) for
                              // layers that transform their own input (cin_pad <= wf_phased_maxk at load time), or null
+    float* wum[4] = {nullptr, nullptr, nullptr, nullptr};   // mixed tile sizes (wino_mixed.hip): weights of the tile types (4,3), (3,4), (3,3) in fragment
+                             // order at [1..3] ([0] = wuc), for zero-padded layers with cin_pad == 256 (the 14x14 maps of stage 3), or null
     float* wuc = nullptr;    // the same in the K-chunk order k_wino_fused streams ([cout_pad/64][cin_pad/8][36][128][4]) or null
 };
 
@@ -61,6 +63,7 @@ struct Options {
     int sk_minunits = 18;         // smallest number of K-tiles a stream-K block may own
     int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
     int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
+    int wf_mixed = 1;             // 1: 14x14 maps are tiled 4+4+3+3 (k_wino_fused_mixed) when the launch gives every CU two blocks or more
     int wf_q = 0;                 // 1: the phased fused launches (in-kernel input transform) run k_wino_fused_q (round-4 experiment: a tie)
     int igemm_tile64 = 0;         // > 0: tile shape forced for large direct convolutions with 64 output channels (1..4, ffr_conv_desc.tile)
     int combine_v = 1;            // 1: a bottleneck's combine also writes V for the next conv1 when that runs k_wino_fused from V
@@ -200,6 +203,7 @@ struct ConvCall {
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
     int wino_mode = -1;                            // -1 auto (option "wino"; the form of the fused kernel from wino_fused_choice), 0 never, 1 Winograd in k_wino_fused (32 x 64 blocks), 2 Winograd as transform kernels + batched GEMM, 3 k_wino_fused with 32 x 32 blocks
     int wino_stage = 0;                            // 0 whole conv; 1 stop after the GEMM (M stays in winoM); 2 V is ready in winoV
+    bool v_mixed = false;                          // with wino_stage 2: V is in the four-region layout of wino_mixed.hip (k_combine_in_mixed wrote it)
     bool v_chunked = false;                        // with wino_stage 2: V is in the K-chunked fragment order of k_wino_fused (wino_accepts_ready_v)
     bool* took_wino = nullptr;                     // set to true when the Winograd path ran
     float* tile_sums = nullptr;                    // Winograd path only: per-tile sums of the stored outputs [T][cout_pad]
@@ -208,6 +212,7 @@ struct ConvCall {
 
 int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long T, double x_bytes, int wino_mode);
 bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap);
+bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode);
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse = -1.0);
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st);
 

@@ -108,6 +108,37 @@ bool wino_fused_q_ok(const WinoFusedArgs& a);
 hipError_t launch_wino_fused_q(WinoFusedArgs a, hipStream_t stream);
 inline size_t wino_chunked_floats(long long T, int cin_pad) { return (size_t)((T + 31) / 32) * 32 * 36 * cin_pad; }
 
+// ---- wino_mixed.hip: exact tilings with tiles of 4 and 3 outputs per dimension (14 = 4+4+3+3, 7 = 4+3) ------------
+// tile type tau = 2 * (MR == 3) + (MC == 3): (4,4), (4,3), (3,4), (3,3) with 36 / 30 / 30 / 25 xi, padded to 36 / 32 / 32 / 28
+struct WinoMixedGeom { int n4, o4[2], n3, o3[2]; };      // per dimension: origins of the 4-output and of the 3-output segments
+struct WinoInMixedArgs {
+    const float* x; float* V[4];
+    int N, H, W, pitch, nkc;
+    WinoMixedGeom g;
+    int goff[4];                            // first tile group (= block column) of each type
+    long long T[4];
+};
+struct WinoMixedArgs {
+    const float* V[4];                      // in: V[0] = base of the four regions (wino_mixed_v_floats); the launcher fills the rest
+    const float* U[4];                      // weights per type in fragment order [cout_pad/64][K chunk][XP][128 pieces][4]
+    const float* bias; const float* slope; const float* resid; float* out; float* tile_sums;
+    int N, H, W, nkc;
+    int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
+    WinoMixedGeom g;                        // filled by the launcher, as everything below
+    int mbn[4], boff[4], nbn, tpi_off[4], tpi_total;
+    long long T[4];
+};
+bool wino_mixed_geom(int H, int W, WinoMixedGeom* g);
+int wino_mixed_x(int tau);
+int wino_mixed_xp(int tau);
+size_t wino_mixed_v_floats(const WinoMixedGeom& g, int N, int cin_pad, size_t off[4]);
+int wino_mixed_blocks(int N, int H, int W, int cout_pad);
+hipError_t wino_mixed_init();
+hipError_t launch_wino_in_mixed(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, hipStream_t stream);
+hipError_t launch_wino_fused_mixed(WinoMixedArgs a, hipStream_t stream);
+hipError_t launch_combine_in_mixed(const float* res, const float* scale, const float* sh, float* out, float* V, int N, int H, int W,
+                                   int C, hipStream_t stream);
+
 // ---- measurement: what the fp32 matrix cores deliver on THIS device (probe.hip) ------------------------
 // `blocks` x 256 threads, each wave issues iters x 16 independent-accumulator v_mfma_f32_32x32x2_f32 on random
 // register operands; stamps[block*4 + {0,1,2,3}] = s_memtime begin/end, s_memrealtime begin/end of wave 0

@@ -307,6 +307,32 @@ def test_encoder_forward_and_trunk_112x96_full_size(engine, state_dicts):
         assert torch.isfinite(fm).all()
 
 
+@pytest.mark.parametrize('case', [(8, 256, True, False), (70, 256, True, True), (33, 512, False, False)])
+def test_mixed_tile_sizes_match_direct_and_torch(engine, case):
+    """The exact 4+4+3+3 tiling of 14x14 maps (wino_mixed.hip: tile types F(4x4), F(4x3), F(3x4), F(3x3); use_wino = 4 forces
+    it) vs torch conv2d, vs the direct implicit GEMM and vs the padded F(4x4) kernel: whole tile groups, a partly empty last
+    group (70 images: 280 tiles per type), PReLU, residual, 256 and 512 output channels."""
+    N, cout, prelu, resid = case
+    g = torch.Generator().manual_seed(4242 + N)
+    x = torch.randn(N, 14, 14, 256, generator=g)
+    w = torch.randn(cout, 256, 3, 3, generator=g) / (256 * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    slope = torch.rand(cout, generator=g) * 0.3 + 0.1 if prelu else None
+    r = torch.randn(N, 14, 14, cout, generator=g) if resid else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, bias, 1, 1)
+    if prelu:
+        ref = F.prelu(ref, slope)
+    if resid:
+        ref = ref + r.permute(0, 3, 1, 2)
+    rd = r.cuda() if resid else None
+    got_d = engine.op_conv3x3(x.cuda(), w, bias, slope, 0, 0, rd).permute(0, 3, 1, 2).cpu()
+    got_4 = engine.op_conv3x3(x.cuda(), w, bias, slope, 0, 1, rd).permute(0, 3, 1, 2).cpu()
+    got_m = engine.op_conv3x3(x.cuda(), w, bias, slope, 0, 4, rd).permute(0, 3, 1, 2).cpu()
+    assert rel(got_d, ref) < OP_TOL
+    assert rel(got_m, ref) < 1e-4 and rel(got_m, got_d) < 1e-4 and rel(got_m, got_4) < 1e-4
+    assert not torch.equal(got_m, got_4)            # it really is another arithmetic
+
+
 @pytest.mark.parametrize('B', [256, 512])
 def test_two_call_shell_path_full_size(engine, state_dicts, B):
     """The path the reference's UNCHANGED calculate_distance takes through the shells (lfw_eval.py:241-244):
@@ -793,7 +819,7 @@ def test_experiment_knobs_keep_parity(tmp_path):
                         ('sepool', {'FFR_OPT_SE_MAXTILES': '0'}), ('unfused', {'FFR_OPT_WINO_FUSED': '0'}),
                         ('phased256', {'FFR_OPT_WF_PHASED_MAXK': '256'}), ('direct', {'FFR_OPT_WINO': '0'}),
                         ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nocombinev', {'FFR_OPT_COMBINE_V': '0'}),
-                        ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'}), ('qform', {'FFR_OPT_WF_Q': '1'}),
+                        ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'}), ('qform', {'FFR_OPT_WF_Q': '1'}), ('nomixed', {'FFR_OPT_WF_MIXED': '0'}),
                         ('tile64', {'FFR_OPT_IGEMM_TILE64': '4'})):
         got = run(name, **knobs)
         for k in ('f_new', 'f'):

@@ -44,13 +44,19 @@ def main():
     n = b['config']['batch_per_gpu']
     calls = ns = 0
     for row in csv.DictReader(open(stats)):
-        if 'k_wino_fused' in row['Name']:
+        if 'k_wino_fused' in row['Name']:          # k_wino_fused<.,.>, k_wino_fused_mixed (and k_wino_fused_q when selected)
             calls += int(row['Calls'])
             ns += int(row['TotalDurationNs'])
     avg_us = ns / calls / 1e3
     L = fused_layers()
     ex = us = 0.0
     for h, cin, cout in L:
+        if h == 14 and cin == 256 and n * 16 // 32 * (pad(cout, 64) // 64) >= 512:
+            # exact 4+4+3+3 tiling (wino_mixed.hip): four tile types, 4 tiles each per image, 36 / 30 / 30 / 25 xi padded to 36 / 32 / 32 / 28
+            for x, xp in ((36, 36), (30, 32), (30, 32), (25, 28)):
+                ex += 2 * xp * pad(4 * n, 32) * pad(cin, 32) * pad(cout, 64)
+                us += 2 * x * 4 * n * cin * cout
+            continue
         t = n * math.ceil(h / 4) ** 2
         ex += 2 * 36 * pad(t, 32) * pad(cin, 32) * pad(cout, 64)
         us += 2 * n * h * h * 9 * cin * cout / 4
