@@ -626,8 +626,8 @@ def main():
                                            'ALL launches of a step = %.2f GB (HBM-bound classes alone: %.2f GB)'
                                            % (compulsory_gb, hbm_bytes / nprof / 1e9))
         roof = {'bound': 'mfma',
-                'kernel': 'k_wino_fused (the 36 fp32-MFMA GEMMs + output transform + epilogue of a Winograd F(4x4,3x3) '
-                          'convolution in one launch)',
+                'kernel': 'k_wino_fused / k_wino_fused_mixed (the fp32-MFMA GEMMs of every xi + output transform + epilogue of a '
+                          'Winograd convolution in one launch: F(4x4,3x3) tiles, on 14x14 maps the exact 4+4+3+3 tiling)',
                 'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 # the roofline fraction three ways, all for the dominant kernel over its own hipEvent time:
                 'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),                       # FLOPs EXECUTED, padding included
@@ -635,9 +635,11 @@ def main():
                 'frac_algorithmic_survey_8d': round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),  # whole step, direct-convolution count
                 'traffic': tr.get('hbm_bytes_per_launch'),              # HBM bytes per launch of the dominant kernel (PMC), or null
                 'traffic_ratio_vs_compulsory': ratio,                   # all kernels: PMC bytes per step / compulsory bytes per step
-                'note': 'frac: FLOPs the matrix cores EXECUTED in k_wino_fused (2*36*ceil(T/32)*32*cin_pad*cout_pad per launch) / its '
-                        'hipEvent time / peak.  frac_useful: the same without padding (tiles hanging over 14x14 and 7x7 maps, '
-                        'rows beyond T, zero-padded channels) = the direct-convolution FLOPs of those layers / 4.  '
+                'note': 'frac: FLOPs the matrix cores EXECUTED in the fused Winograd launches (2*xi*ceil(T/32)*32*cin_pad*cout_pad per '
+                        'launch and tile type, xi = 36, or 36/32/32/28 for the four tile types of a 14x14 map) / their hipEvent '
+                        'time / peak.  frac_useful: the same without padding (tiles hanging over 7x7 maps, padded xi, rows beyond T, '
+                        'zero-padded channels).  Executing FEWER FLOPs for the same result (the exact tiling of 14x14 maps, round '
+                        '4) lowers frac and raises frac_useful and the throughput.  '
                         'frac_algorithmic_survey_8d: embeddings/s x 15.1427 GFLOP (SURVEY 8d counts every convolution as a '
                         'direct one) / peak for the WHOLE step; it exceeds 1 because Winograd F(4x4,3x3) executes 36 instead of '
                         '144 multiplies per 4x4 output tile and channel pair (results verified in this process: parity_checked)',

@@ -201,7 +201,7 @@ struct ConvCall {
     float* partial; size_t partial_cap;   // floats
     int* tickets; size_t tickets_cap;
     float* winoV; float* winoM; size_t wino_cap;   // Winograd scratch (floats each), or null
-    int wino_mode = -1;                            // -1 auto (option "wino"; the form of the fused kernel from wino_fused_choice), 0 never, 1 Winograd in k_wino_fused (32 x 64 blocks), 2 Winograd as transform kernels + batched GEMM, 3 k_wino_fused with 32 x 32 blocks
+    int wino_mode = -1;                            // -1 auto (option "wino"; the form of the fused kernel from wino_fused_choice), 0 never, 1 Winograd in k_wino_fused (32 x 64 blocks), 2 Winograd as transform kernels + batched GEMM, 3 k_wino_fused with 32 x 32 blocks, 4 the exact 4+4+3+3 tiling of a 14x14 map (k_wino_fused_mixed; cin_pad 256, zero padding)
     int wino_stage = 0;                            // 0 whole conv; 1 stop after the GEMM (M stays in winoM); 2 V is ready in winoV
     bool v_mixed = false;                          // with wino_stage 2: V is in the four-region layout of wino_mixed.hip (k_combine_in_mixed wrote it)
     bool v_chunked = false;                        // with wino_stage 2: V is in the K-chunked fragment order of k_wino_fused (wino_accepts_ready_v)

@@ -176,6 +176,9 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
  *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
  *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
+ *   "wf_mixed" (1)        1: 14x14 maps (stage 3) are tiled exactly, 4+4+3+3 per dimension, with four tile types F(4x4) / F(4x3) /
+ *                         F(3x4) / F(3x3) in one launch (k_wino_fused_mixed) whenever every CU gets two blocks or more; 0: padded
+ *                         F(4x4) tiles only.  Set BEFORE ffr_load_encoder (the three extra weight sets are packed at load time)
  *   "wf_q" (0)            1: launches that transform their own input run k_wino_fused_q (a wave owns all 36 xi of a
  *                         16-channel slice, v_mfma_f32_16x16x4_f32, output transform in registers): the round-4
  *                         experiment, as fast as k_wino_fused<1, 2> and not faster
@@ -223,8 +226,9 @@ int ffr_op_conv(ffr_handle* h, const ffr_conv_desc* d, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution from RAW weights (host, [cout][cin][3][3] as torch stores them,
  * bias[cout], optional PReLU slope[cout]) on x[N,H,W,cin] NHWC (device, cin % 32 == 0), packed on
  * the fly.  use_wino: 0 = direct implicit GEMM, 1 = Winograd F(4x4,3x3) with GEMM and output transform in one kernel
- * (k_wino_fused; input transform inside it for cin <= 128), 2 = Winograd as transform kernels around a batched GEMM.  Test hook
- * that holds both paths to torch's conv2d.  out[N,H,W,cout] NHWC device, cout % 4 == 0.         */
+ * (k_wino_fused; input transform inside it for cin <= 128), 2 = Winograd as transform kernels around a batched GEMM, 3 = k_wino_fused
+ * with 32 x 32 blocks, 4 = the exact 4+4+3+3 tiling of a 14x14 map with 256 input channels (k_wino_fused_mixed).  Test hook
+ * that holds every path to torch's conv2d.  out[N,H,W,cout] NHWC device, cout % 4 == 0.         */
 int ffr_op_conv3x3(ffr_handle* h, const float* x_nhwc, int N, int H, int W, int cin,
                    const float* w_host, const float* bias_host, const float* slope_host, int cout,
                    int pad_mode, int use_wino, const float* resid_nhwc, float* out_nhwc, void* stream);
