@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     auto fetch = [&](int step) {
         const long long p = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX + (tid >> 2);
         const bool pv = p < total;
-        const int n = pv ? (int)(p / HW) : 0;
-        const int rem = pv ? (int)(p - (long long)n * HW) : 0;
-        const int h = rem / W, wq = rem - h * W;
+        const int n = pv ? (int)((unsigned)p / (unsigned)HW) : 0;      // p < N * H * W < 2^31 (launch_stem): 32-bit divisions
+        const int rem = pv ? (int)((unsigned)p - (unsigned)n * (unsigned)HW) : 0;
+        const int h = (int)((unsigned)rem / (unsigned)W), wq = rem - h * W;
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
             float v = 0.f;
@@ -115,6 +115,7 @@ hipError_t launch_stem(const float* x, const unsigned char* xu8, const unsigned 
                        const float* bias, const float* slope, float* out, int N, int H, int W, hipStream_t stream, const float* x2, int n_split) {
     const long long total = (long long)N * H * W;
     const long long per_block = (long long)STEM_PIX * STEM_STEPS;
+    if (total >= 0x7fffffffLL) return hipErrorInvalidValue;      // the kernel decomposes pixel indices with 32-bit divisions
     const unsigned blocks = (unsigned)((total + per_block - 1) / per_block);
     if (!x2) n_split = N;
     if (xu8) hipLaunchKernelGGL(k_stem<true>, dim3(blocks), dim3(256), 0, stream, x, xu8, flip, w, bias, slope, out, N, H, W, x2, n_split);
@@ -266,39 +267,46 @@ hipError_t launch_se_fc(const float* part, int N, int S, int HW, int C, const fl
 // out = res * se_scale + shortcut    (bottleneck_IR_SE.forward, model_ir_se50.py:73-76;
 // MaxPool2d(1, stride) shortcut = strided subsample, :60)
 // ---------------------------------------------------------------------------------------
+// One thread per 16-byte item: pixel m, channel quad.  All index arithmetic is 32-bit with the channel count a power of
+// two (a 64-bit division is ~100 instructions; two of them per item made this "HBM-bound" pass arithmetic-bound: round 4).
 __global__ __launch_bounds__(256) void k_combine(const float* __restrict__ res, const float* __restrict__ scale,
                                                 const float* __restrict__ sc, const float* __restrict__ x,
-                                                float* __restrict__ out, int HoWo, int Wo, int C, int stride,
-                                                long long total4) {
-    const int cq = C >> 2;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long long)gridDim.x * 256) {
-        const long long m = idx / cq;
-        const int c4 = (int)(idx - m * cq) * 4;
-        const int n = (int)(m / HoWo);
-        const f32x4 r = *reinterpret_cast<const f32x4*>(res + m * C + c4);
+                                                float* __restrict__ out, unsigned HoWo, unsigned Wo, int C, int stride,
+                                                unsigned total4, int cq_shift) {
+    const unsigned cq_mask = (1u << cq_shift) - 1u;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total4; idx += gridDim.x * 256u) {
+        const unsigned m = idx >> cq_shift;
+        const unsigned c4 = (idx & cq_mask) * 4u;
+        const unsigned n = m / HoWo;
+        const size_t off = (size_t)m * C + c4;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(res + off);
         const f32x4 s = scale ? *reinterpret_cast<const f32x4*>(scale + (size_t)n * C + c4) : (f32x4){1.f, 1.f, 1.f, 1.f};
         f32x4 sh;
         if (sc) {
-            sh = *reinterpret_cast<const f32x4*>(sc + m * C + c4);
+            sh = *reinterpret_cast<const f32x4*>(sc + off);
         } else if (stride == 1) {
-            sh = *reinterpret_cast<const f32x4*>(x + m * C + c4);
+            sh = *reinterpret_cast<const f32x4*>(x + off);
         } else {
-            const int rem = (int)(m - (long long)n * HoWo);
-            const int ho = rem / Wo, wo = rem - ho * Wo;
-            const long long pin = ((long long)n * (HoWo / Wo) * stride + (long long)ho * stride) * (Wo * stride) + wo * stride;
+            const unsigned rem = m - n * HoWo;
+            const unsigned ho = rem / Wo, wo = rem - ho * Wo;
+            const size_t pin = ((size_t)n * (HoWo / Wo) * stride + (size_t)ho * stride) * (Wo * stride) + wo * stride;
             sh = *reinterpret_cast<const f32x4*>(x + pin * C + c4);
         }
-        *reinterpret_cast<f32x4*>(out + m * C + c4) = r * s + sh;
+        *reinterpret_cast<f32x4*>(out + off) = r * s + sh;
     }
 }
 
 hipError_t launch_combine(const float* res, const float* scale, const float* sc, const float* x, float* out,
                           int N, int Ho, int Wo, int C, int stride, hipStream_t stream) {
     const long long total4 = (long long)N * Ho * Wo * (C >> 2);
+    const int cq = C >> 2;
+    int shift = 0;
+    while ((1 << shift) < cq) ++shift;
+    if ((1 << shift) != cq || total4 >= 0x7fffffffLL || C % 4) return hipErrorInvalidValue;      // C in {64, 128, 256, 512}
     unsigned blocks = (unsigned)((total4 + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, stream, res, scale, sc, x, out, Ho * Wo, Wo, C, stride,
-                       total4);
+    hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, stream, res, scale, sc, x, out, (unsigned)(Ho * Wo), (unsigned)Wo, C, stride,
+                       (unsigned)total4, shift);
     return hipGetLastError();
 }
 

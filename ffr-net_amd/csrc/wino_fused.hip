@@ -43,9 +43,11 @@ __global__ __launch_bounds__(256) void k_wino_in_c(const float* __restrict__ x, 
         for (int xi = 0; xi < 36; ++xi) *reinterpret_cast<f32x4*>(vout + xi * 256) = (f32x4){0.f, 0.f, 0.f, 0.f};
         return;
     }
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const int n = (int)(t / ((long long)tw * th));
+    const unsigned tu = (unsigned)t, tpi = (unsigned)(tw * th);       // T < 2^31: 32-bit divisions
+    const int n = (int)(tu / tpi);
+    const unsigned tr = tu - (unsigned)n * tpi;
+    const int ty = (int)(tr / (unsigned)tw);
+    const int tx = (int)(tr - (unsigned)ty * (unsigned)tw);
     const int h0 = ty * 4 - 1, w0 = tx * 4 - 1;
     const float* xn = x + (size_t)n * H * W * pitch + c4;
     f32x4 tmp[6][6];
@@ -202,7 +204,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // ---- the fused GEMM + output transform ------------------------------------------------------------------------
 constexpr int WF_EPI_FLOATS = 36 * 32 * 32;  // the epilogue's E[xi][tile][32 channels] (147,456 B); the K loop uses no LDS
-constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8) * 4;   // + bias table + tile table = 150,784 B
+constexpr int WF_LDS_BYTES = (WF_EPI_FLOATS + 9 * 64 + 32 * 8 + 32 * 12) * 4;   // + bias table + tile table + patch-offset table = 152,320 B
 
 // MODE 0 (PHASED = false): V comes pre-transformed from k_wino_in_c (global memory, fragment order).
 // MODE 1 (PHASED = true) : the block transforms its own input, 32 channels (4 K chunks) at a time, into LDS (147 KB, the
@@ -252,10 +254,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         const long long t = (long long)mb * 32 + tid;
         int pix0 = 0, vrc = 0, br = 0, bc = 0, ibase = 0, h0 = 0, w0 = 0;
         if (t < a.T) {
-            const int tiles_img = a.th * a.tw;
-            const int n = (int)(t / tiles_img);
-            const int tr = (int)(t - (long long)n * tiles_img);
-            const int ty = tr / a.tw, tx = tr - ty * a.tw;
+            const unsigned tiles_img = (unsigned)(a.th * a.tw);        // T < 2^31 (run_conv): 32-bit divisions
+            const int n = (int)((unsigned)t / tiles_img);
+            const int tr = (int)((unsigned)t - (unsigned)n * tiles_img);
+            const int ty = (int)((unsigned)tr / (unsigned)a.tw), tx = tr - ty * a.tw;
             pix0 = (n * a.H + ty * 4) * a.W + tx * 4;
             ibase = n * a.H * a.W; h0 = ty * 4 - 1; w0 = tx * 4 - 1;
             const int vr = a.H - ty * 4 < 4 ? a.H - ty * 4 : 4, vc = a.W - tx * 4 < 4 ? a.W - tx * 4 : 4;
@@ -266,6 +268,27 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         }
         s_tile[tid * 8 + 0] = pix0; s_tile[tid * 8 + 1] = vrc; s_tile[tid * 8 + 2] = br; s_tile[tid * 8 + 3] = bc;
         s_tile[tid * 8 + 4] = ibase; s_tile[tid * 8 + 5] = h0; s_tile[tid * 8 + 6] = w0;
+        if constexpr (PHASED) {
+            // byte offsets of the 6 patch rows / columns of this tile (without the lane's channel quad), or a value past the end
+            // of the tensor for a row / column outside the map (zero padding) or a tile beyond T: the phases re-read them
+            // from here (12 LDS reads) instead of recomputing them among the MFMAs of every phase's last K chunk (~70 VALU)
+            unsigned* const so = reinterpret_cast<unsigned*>(s_tile + 32 * 8) + tid * 12;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int hi = h0 + i, wi = w0 + i;
+                bool rok, cok;
+                if (a.pad_mode == 1) {
+                    hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi); if (hi < 0) hi = 0;
+                    wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi); if (wi < 0) wi = 0;
+                    rok = vrc != 0; cok = true;
+                } else {
+                    rok = vrc != 0 && (unsigned)hi < (unsigned)a.H;
+                    cok = (unsigned)wi < (unsigned)a.W;
+                }
+                so[i] = rok ? (unsigned)((ibase + hi * a.W) * a.in_pitch) * 4u : 0x40000000u;
+                so[6 + i] = cok ? (unsigned)(wi * a.in_pitch) * 4u : 0x40000000u;
+            }
+        }
     }
 
     // operand streams of this wave: one 16-byte fragment per lane, xi and K chunk (lane-linear in memory)
@@ -386,23 +409,12 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // start of every phase's last K chunk (live from there to the next phase's loads; 24 such registers held across all
     // MFMA chunks spilled accumulators in round 2)
     unsigned ro[6], co[6];
+    const unsigned* const s_off = reinterpret_cast<const unsigned*>(s_tile + 32 * 8) + ttl * 12;
     auto offsets = [&]() {
-        const int tvrc = s_tile[ttl * 8 + 1];
-        const int tib = s_tile[ttl * 8 + 4], th0 = s_tile[ttl * 8 + 5], tw0 = s_tile[ttl * 8 + 6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            int hi = th0 + i, wi = tw0 + i;
-            bool rok, cok;
-            if (a.pad_mode == 1) {
-                hi = hi < 0 ? -hi : (hi >= a.H ? 2 * a.H - 2 - hi : hi); if (hi < 0) hi = 0;
-                wi = wi < 0 ? -wi : (wi >= a.W ? 2 * a.W - 2 - wi : wi); if (wi < 0) wi = 0;
-                rok = tvrc != 0; cok = true;
-            } else {
-                rok = tvrc != 0 && (unsigned)hi < (unsigned)a.H;
-                cok = (unsigned)wi < (unsigned)a.W;
-            }
-            ro[i] = rok ? (unsigned)((tib + hi * a.W) * a.in_pitch + tq * 4) * 4u : OOB;
-            co[i] = cok ? (unsigned)(wi * a.in_pitch) * 4u : OOB;
+            ro[i] = s_off[i] + (unsigned)tq * 16u;
+            co[i] = s_off[6 + i];
         }
     };
     offsets();

@@ -38,6 +38,28 @@ __device__ __forceinline__ void at6(const f32x4 m[6], f32x4 y[4]) {
     y[3] = d12 + 8.f * d34 + m[5];
 }
 
+// item idx = (tile t, channel quad): t = idx / cq, then t -> (image n, tile row ty, tile column tx).  The items of every launch
+// this library makes are fewer than 2^31, for which everything is 32-bit arithmetic (a 64-bit division is ~100 instructions, and
+// there were four of them per item); the 64-bit form stays as the general case.
+__device__ __forceinline__ void wino_item(long long idx, int cq, int tw, int th, long long* t, int* c4, int* tx, int* ty, long long* n) {
+    if ((idx >> 31) == 0) {
+        const unsigned i = (unsigned)idx;
+        const unsigned tt = i / (unsigned)cq;
+        *c4 = (int)(i - tt * (unsigned)cq) * 4;
+        const unsigned tpi = (unsigned)(tw * th);
+        const unsigned nn = tt / tpi, tr = tt - nn * tpi;
+        const unsigned y = tr / (unsigned)tw;
+        *t = tt; *n = nn; *ty = (int)y; *tx = (int)(tr - y * (unsigned)tw);
+    } else {
+        const long long tt = idx / cq;
+        *c4 = (int)(idx - tt * cq) * 4;
+        *t = tt;
+        *tx = (int)(tt % tw);
+        *ty = (int)((tt / tw) % th);
+        *n = tt / ((long long)tw * th);
+    }
+}
+
 // one thread = one tile x 4 channels; lanes run along the channels (16-B coalesced)
 template <int PAD_MODE>
 __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int N, int H,
@@ -45,11 +67,9 @@ __global__ __launch_bounds__(256) void k_wino_in(const float* __restrict__ x, fl
     const int cq = cin_pad >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * cq) return;
-    const long long t = idx / cq;
-    const int c4 = (int)(idx - t * cq) * 4;
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const int n = (int)(t / ((long long)tw * th));
+    long long t, nl; int c4, tx, ty;
+    wino_item(idx, cq, tw, th, &t, &c4, &tx, &ty, &nl);
+    const int n = (int)nl;
     const int h0 = ty * 4 - 1, w0 = tx * 4 - 1;
     const float* xn = x + (size_t)n * H * W * pitch + c4;
     f32x4 tmp[6][6];
@@ -96,11 +116,9 @@ __global__ __launch_bounds__(256) void k_wino_out(const WinoOutArgs a) {
     const int cq = a.cout_pad >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= a.T * cq) return;
-    const long long t = idx / cq;
-    const int c4 = (int)(idx - t * cq) * 4;
-    const int tx = (int)(t % a.tw);
-    const int ty = (int)((t / a.tw) % a.th);
-    const int n = (int)(t / ((long long)a.tw * a.th));
+    long long t, nl; int c4, tx, ty;
+    wino_item(idx, cq, a.tw, a.th, &t, &c4, &tx, &ty, &nl);
+    const int n = (int)nl;
     const float* min = a.M + (size_t)t * a.cout_pad + c4;
     const size_t plane = (size_t)a.T * a.cout_pad;
     f32x4 tmp[4][6];      // A^T applied to the columns: [out row][j]
@@ -220,11 +238,8 @@ __global__ __launch_bounds__(256) void k_wino_dout(const float* __restrict__ dy,
     const int cq = Cp >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * cq) return;
-    const long long t = idx / cq;
-    const int c4 = (int)(idx - t * cq) * 4;
-    const int tx = (int)(t % tw);
-    const int ty = (int)((t / tw) % th);
-    const long long n = t / ((long long)tw * th);
+    long long t, n; int c4, tx, ty;
+    wino_item(idx, cq, tw, th, &t, &c4, &tx, &ty, &n);
     const float* base = dy + (size_t)n * H * W * Cp + c4;
     f32x4 tmp[6][4];     // A applied to the columns: [i][col]
 #pragma unroll
