@@ -12,7 +12,8 @@
 // Work split of a block (256 threads, one wave per SIMD): wave w owns xi in [9w, 9w+9) for all 32 tiles x 64
 // channels: 18 accumulator tiles of 32x32 = 288 registers.  Nothing is shared between the waves during the K loop:
 // wave w needs only V[xi] and U[xi] of its own xi, and the MFMA operand of a lane is 16 contiguous bytes (4 k-values of
-// one row), so V and U are stored in exactly that order -- [group][8-channel K chunk][xi][64 lanes][4 floats] -- and a
+// one row; since round 4 U is the A operand and V the B operand, so that a lane ends up with one tile and four consecutive
+// channels per register quad), so V and U are stored in exactly that order -- [group][8-channel K chunk][xi][64 lanes][4 floats] -- and a
 // fragment is ONE coalesced global_load_dwordx4 per lane straight into the register the MFMA reads: no LDS, no
 // barrier, no LDS-DMA in the K loop.  Lane l carries row l & 31 and k = 4 (l >> 5) + e for the e-th of the four
 // v_mfma_f32_32x32x2_f32 a load feeds (A and B use the same order).  Nine fragment slots per wave are reloaded one step
@@ -352,8 +353,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
             for (int g = 0; g < 4 * NT; ++g) {
                 const int e = g / NT, nt = g % NT;
-                if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
-                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
+                if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(nt ? b1[e] : b0[e], av[e], acc[j][nt], 0, 0, 0);
+                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(nt ? b1[e] : b0[e]), "v"(av[e]));
                 // the step's three loads go out back to back in ONE MFMA gap: an MFMA whose gap carries vector-memory
                 // instructions issues ~8 cycles late plus ~14 per load (measured: 5.30k cycles per K chunk with one load in
                 // each of three gaps, 5.15k with three loads in one gap, 4.70k without loads)
@@ -485,8 +486,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
                 for (int g = 0; g < 4 * NT; ++g) {
                     const int e = g / NT, nt = g % NT;
-                    if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
-                    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
+                    if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(nt ? b1[e] : b0[e], av[e], acc[j][nt], 0, 0, 0);
+                    else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(nt ? b1[e] : b0[e]), "v"(av[e]));
                     if (c == 3 && j == 0 && g == 0) offsets();
                     if (g == 1) {              // both weight loads of the step in one MFMA gap (see the unphased loop)
 #pragma unroll
@@ -528,8 +529,14 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                smem[((9 * wave + j) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + rowl] = j < 8 ? acc[j][nt][r] : accv[nt][r];
+            for (int q = 0; q < 4; ++q) {
+                // the MFMAs run with A = U, B = V: a lane holds tile rowl and, in registers 4q..4q+3, the FOUR CONSECUTIVE channels
+                // 8q + 4 hsel + 0..3 -> one 16-byte LDS write (36 per pass instead of 144 dword writes); the 16-byte chunk index is
+                // XOR-ed with the tile so that 8 lanes (8 tiles, one chunk) hit 8 different bank columns; the reader applies the same XOR
+                const f32x16& t16 = j < 8 ? acc[j < 8 ? j : 0][nt] : accv[nt];
+                *reinterpret_cast<f32x4*>(smem + ((9 * wave + j) * 32 + rowl) * 32 + (((2 * q + hsel) ^ (rowl & 7)) * 4)) =
+                    (f32x4){t16[4 * q], t16[4 * q + 1], t16[4 * q + 2], t16[4 * q + 3]};
+            }
         __syncthreads();
         if (FFR_TRACE_ON(a.trace) && !PHASED) se[2 * nt] = __builtin_amdgcn_s_memtime();
         // one (tile, 4 channels) per thread: a wave-instruction reads / stores 8 tiles x 128 bytes
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
         if (vrc != 0) {                                                 // else: tile beyond T
             const int pix0 = s_tile[tl * 8 + 0];
             const int vr = vrc & 0xff, vc = vrc >> 8;
-            const f32x4* e = reinterpret_cast<const f32x4*>(smem + tl * 32 + 4 * cq);
+            const f32x4* e = reinterpret_cast<const f32x4*>(smem + tl * 32 + 4 * (cq ^ (tl & 7)));
             f32x4 y[4][4];
             {
                 f32x4 tmp[4][6];

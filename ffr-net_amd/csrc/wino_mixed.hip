@@ -323,8 +323,8 @@ __device__ __forceinline__ void fused_mixed_body(const WinoMixedArgs& a, int tau
 #pragma unroll
             for (int g = 0; g < 4 * NT; ++g) {
                 const int e = g / NT, nt = g % NT;
-                if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], nt ? b1[e] : b0[e], acc[j][nt], 0, 0, 0);
-                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(av[e]), "v"(nt ? b1[e] : b0[e]));
+                if (j < 8) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(nt ? b1[e] : b0[e], av[e], acc[j][nt], 0, 0, 0);
+                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(accv[nt]) : "v"(nt ? b1[e] : b0[e]), "v"(av[e]));
                 if (g == 1) {
 #pragma unroll
                     for (int part = 0; part <= NT; ++part) {
@@ -354,16 +354,18 @@ __device__ __forceinline__ void fused_mixed_body(const WinoMixedArgs& a, int tau
         for (int j = 0; j < S; ++j) {
             const int e = S * wave + j;
             if (e < X) {
+                const f32x16& t16 = j < 8 ? acc[j < 8 ? j : 0][nt] : accv[nt];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    smem[(e * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + rowl] = j < 8 ? acc[j < 8 ? j : 0][nt][r] : accv[nt][r];
+                for (int q = 0; q < 4; ++q)         // lane = tile rowl, registers 4q..4q+3 = channels 8q + 4 hsel + 0..3 (A = U, B = V): see k_wino_fused
+                    *reinterpret_cast<f32x4*>(smem + (e * 32 + rowl) * 32 + (((2 * q + hsel) ^ (rowl & 7)) * 4)) =
+                        (f32x4){t16[4 * q], t16[4 * q + 1], t16[4 * q + 2], t16[4 * q + 3]};
             }
         }
         __syncthreads();
         const int tl = (lane >> 3) + 8 * wave;
         if (s_tile[tl * 8 + 1] != 0) {                                  // else: tile beyond T
             const int pix0 = s_tile[tl * 8 + 0];
-            const f32x4* ev = reinterpret_cast<const f32x4*>(smem + tl * 32 + 4 * cq);
+            const f32x4* ev = reinterpret_cast<const f32x4*>(smem + tl * 32 + 4 * (cq ^ (tl & 7)));
             f32x4 tmp[MR][AC];
 #pragma unroll
             for (int j = 0; j < AC; ++j) {
