@@ -34,6 +34,7 @@ python3 tools/wf_trace.py 2>&1 | grep "wf trace" > "$O/${RD}_wino_fused_phase_tr
 FFR_OPT_WF_Q=1 python3 tools/wf_trace.py 2>&1 | grep "wf trace" | grep -A1 "q form" | grep -v "^--" > "$O/${RD}_exp_wf_q_form_phase_trace.txt" || true
 python3 tools/stride2_experiments.py 256 2>/dev/null | grep -v "amdgpu.ids" > "$O/${RD}_exp_stride2_polyphase_lower_bound.txt" || true
 for q in 1 0; do python3 bench.py --no-cpu-baseline --no-secondary --opt wf_q=$q > "$O/${RD}_exp_bench_wf_q$q.json" 2>> "$O/bench.err" || true; done
+for m in 1 0; do python3 bench.py --no-cpu-baseline --no-secondary --opt wf_mixed=$m > "$O/${RD}_exp_bench_wf_mixed$m.json" 2>> "$O/bench.err" || true; done
 for t in 0 4; do python3 bench.py --no-cpu-baseline --no-secondary --opt igemm_tile64=$t > "$O/${RD}_exp_bench_igemm_tile64_$t.json" 2>> "$O/bench.err" || true; done
 TRACE=igemm_trace python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > "$O/${RD}_igemm_trace.txt" || true
 cd /tmp && export TMPDIR=/tmp
