@@ -263,11 +263,12 @@ def test_batch_independence_full_size(engine, state_dicts):
     assert torch.equal(f_new2, f_new) and torch.equal(f2, f)
 
 
-@pytest.mark.parametrize('B', [64, 128, 200, 300])
+@pytest.mark.parametrize('B', [64, 128, 200, 257, 300])
 def test_batch_independence_other_batches(engine, state_dicts, B):
     """128 and 64 images: the per-GPU shard of BASELINE configs[3] on 8 / 16 GPUs, where the planner takes other
     branches than at 256 (32 x 32 block tiles of k_wino_fused for stage 3 / stage 4 / RecNet, 1.5-round launches).
-    200 and 300: batches that are not a power of two -- the fused launches split off a different number of images for
+    257: an odd batch on the exact 4+4+3+3 tiling of the 14x14 maps (wino_mixed.hip: the last tile group of every type is
+    partly empty, the last combine block holds one image).  200 and 300: batches that are not a power of two -- the fused launches split off a different number of images for
     the transform-kernel path (whole rounds of block tiles), tile groups straddle images, the last
     tile group is partly empty.  Every row must match the same image embedded in a batch of 8; a subset is held to
     the oracle."""
