@@ -631,7 +631,10 @@ def main():
                 'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 # the roofline fraction three ways, all for the dominant kernel over its own hipEvent time:
                 'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),                       # FLOPs EXECUTED, padding included
-                'frac_useful': round(dom_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),          # executed minus tile / row / channel padding
+                'frac_useful': round(dom_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),          # executed minus tile / xi / row / channel padding
+                # the round-3-comparable form of the same: the layers' direct-convolution FLOPs / 4 (what an all-F(4x4) tiling without
+                # padding would execute) over the same time -- independent of which tile sizes the kernels really use
+                'frac_useful_f4x4_equivalent': round(dom['flops'] / 4.0 / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 'frac_algorithmic_survey_8d': round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),  # whole step, direct-convolution count
                 'traffic': tr.get('hbm_bytes_per_launch'),              # HBM bytes per launch of the dominant kernel (PMC), or null
                 'traffic_ratio_vs_compulsory': ratio,                   # all kernels: PMC bytes per step / compulsory bytes per step

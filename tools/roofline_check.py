@@ -50,6 +50,7 @@ def main():
     avg_us = ns / calls / 1e3
     L = fused_layers()
     ex = us = 0.0
+    f44 = sum(2 * n * h * h * 9 * cin * cout / 4 for h, cin, cout in L)      # direct-convolution FLOPs / 4: all-F(4x4), no padding
     for h, cin, cout in L:
         if h == 14 and cin == 256 and n * 16 // 32 * (pad(cout, 64) // 64) >= 512:
             # exact 4+4+3+3 tiling (wino_mixed.hip): four tile types, 4 tiles each per image, 36 / 30 / 30 / 25 xi padded to 36 / 32 / 32 / 28
@@ -64,6 +65,7 @@ def main():
     mine = {'launches_per_step': nl, 'avg_launch_us': avg_us,
             'gflop_executed_per_launch': ex / nl / 1e9, 'gflop_useful_per_launch': us / nl / 1e9,
             'frac': ex / nl / (avg_us * 1e-6) / PEAK, 'frac_useful': us / nl / (avg_us * 1e-6) / PEAK,
+            'frac_useful_f4x4_equivalent': f44 / nl / (avg_us * 1e-6) / PEAK,
             'frac_algorithmic_survey_8d': b['value'] / b['n_gpus'] * GFLOP_PER_IMAGE * 1e9 / PEAK}
     bad = 0
     print('%-30s %12s %12s %8s' % ('figure', 'recomputed', 'bench line', 'diff'))
