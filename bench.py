@@ -353,6 +353,92 @@ def cpu_baseline_train(budget_s=15.0):
             'cpu_model': cpu_model()}
 
 
+def train_roofline(eng, step_fn, B, fence, instrument=True, nprof=2, pmc=True):
+    """`roofline` of the training iteration: executed FLOPs of its MFMA kernels over their hipEvent time on the launch
+    stream -- k_wino_fused (encoder + RecNet forward + data gradients), k_igemm / k_gemm_stream (direct and batched-GEMM
+    convolutions, linears) and k_wgrad (weight gradients as TN GEMMs) -- and every launch of the iteration in a kernel class."""
+    if instrument:
+        eng.profile_enable(True)
+    for _ in range(nprof):
+        step_fn()
+    fence()
+    if not instrument:
+        return None
+    st = eng.profile_read()
+    eng.profile_enable(False)
+    sha = so_sha256()
+    cls = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches_per_step': v['launches'] // nprof,
+               'executed_tflops': round(v['flops_executed'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] and v['flops_executed'] else None}
+           for k, v in st.items() if v['launches']}
+    dom = st['wino_fused']
+    dom_s = dom['ms'] * 1e-3
+    dom_tf = dom['flops_executed'] / dom_s / 1e12 if dom['ms'] else 0.0
+    dom_useful_tf = dom['flops_useful'] / dom_s / 1e12 if dom['ms'] else 0.0
+    mf = [st[k] for k in ('wino_fused', 'conv_igemm', 'wgrad')]
+    mf_ms = sum(v['ms'] for v in mf)
+    mf_tf = sum(v['flops_executed'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
+    mf_useful_tf = sum(v['flops_useful'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
+    tot_ms = sum(v['ms'] for v in st.values()) / nprof
+    tr_pmc = pmc_traffic(sha, batch=B, live=False, workload='train') if pmc else {}
+    return {'bound': 'mfma', 'kernel': 'k_wino_fused (frozen encoder + RecNet forward + data gradients)',
+            'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            'frac_useful': round(dom_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            'traffic': tr_pmc.get('hbm_bytes_per_launch'), 'traffic_detail': tr_pmc,
+            'avg_launch_us': round(dom['ms'] * 1e3 / max(1, dom['launches']), 2),
+            'mfma_kernels': {'kernels': 'k_wino_fused + k_igemm/k_gemm_stream + k_wgrad', 'executed_tflops': round(mf_tf, 2),
+                             'frac': round(mf_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                             'frac_useful': round(mf_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                             'ms_per_step': round(mf_ms / nprof, 3)},
+            'hbm_kernels_ms_per_step': round(tot_ms - mf_ms / nprof, 3),
+            'all_kernels_ms_per_step': round(tot_ms, 3),
+            'per_class': cls,
+            'note': 'every launch of the iteration is instrumented (hipEvent pairs on the launch stream): the inference-path '
+                    'classes (encoder), wgrad, and train_bn (BatchNorm statistics / apply / backward), train_loss (loss items, '
+                    'CosFace head), train_optim (zero_grad, clip + Adam), train_xform (Winograd weight / gradient transforms, '
+                    'dgrad packing, reflection folds), train_elem (remaining elementwise / layout kernels); the classes add up '
+                    'to all_kernels_ms_per_step, which contains the dispatch gaps and is slightly more than ms_per_step'}
+
+
+def train_step_line(eng, sd_r, dev, pairs=128, warm=2, iters=5):
+    """SURVEY 8 row N3 / BASELINE configs[4] in the DEFAULT run: whole training iterations of
+    models/trainer.py:139-187 through NativeTrainer on the engine the embedding benchmark just used (its frozen encoder is
+    the one already loaded) -- frozen-encoder forward of clean + occluded images, RecNet train-mode forward, four losses,
+    full backward, clip + Adam -- `warm` untimed + `iters` timed iterations of `pairs` image pairs, then two instrumented
+    ones for the per-class times."""
+    import torch
+    import ffrnet_amd
+    from ffrnet_amd import synth
+    tr = ffrnet_amd.NativeTrainer(eng, sd_r, lr=1e-3)
+    non, ocl, label = synth.synth_train_batch(pairs, seed=500)
+    non, ocl, label = non.to(dev), ocl.to(dev), label.to(dev)
+    for _ in range(warm):
+        tr.step(non, ocl, label)
+    torch.cuda.synchronize()
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        items = tr.step(non, ocl, label)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(torch.isfinite(l) for l in items)
+    roof = train_roofline(eng, lambda: tr.step(non, ocl, label), pairs, torch.cuda.synchronize, pmc=False)
+    return {'workload': 'configs[4] per-GPU shape on 1 GPU: RecNet training iteration (models/trainer.py:139-187), %d image pairs '
+                        '= %d images: frozen IR-SE50 forward, RecNet train-mode forward, 4 losses + CosFace head, full backward, '
+                        'clip + Adam (ffrnet_amd.NativeTrainer.step)' % (pairs, 2 * pairs),
+            'value': round(pairs * iters / dt, 1), 'unit': 'pairs/s', 'ms_per_iteration': round(dt / iters * 1e3, 3),
+            'ms_hipevents': percentiles([a.elapsed_time(b) for a, b in evs]), 'iterations': iters, 'warmup': warm,
+            'frac': roof['mfma_kernels']['frac'], 'frac_useful': roof['mfma_kernels']['frac_useful'],
+            'frac_note': 'executed (useful) FLOPs of ALL MFMA kernels of the iteration (k_wino_fused + k_igemm / k_gemm_stream + '
+                         'k_wgrad) / their hipEvent time / 157.3 TFLOP/s',
+            'mfma_kernels_ms': roof['mfma_kernels']['ms_per_step'], 'all_kernels_ms': roof['all_kernels_ms_per_step'],
+            'per_class_ms': {k: v['ms_per_step'] for k, v in roof['per_class'].items()}}
+
+
 def train_workload(args, world, rank, local, dist):
     """Secondary workload (SURVEY 8 row N3 / BASELINE configs[4]): whole training iterations through NativeTrainer."""
     import torch
@@ -389,52 +475,9 @@ def train_workload(args, world, rank, local, dist):
     assert all(torch.isfinite(l) for l in items)
     roof = None
     if not args.no_roofline:
-        # executed FLOPs of the MFMA kernels of one iteration over their hipEvent time on the launch stream: k_wino_fused
-        # (encoder + RecNet forward + data gradients), k_igemm / k_gemm_stream (direct and batched-GEMM convolutions, linears)
-        # and k_wgrad (weight gradients as TN GEMMs).  tr.step() contains the gradient all-reduce, a COLLECTIVE: every rank
-        # runs the profiled iterations (a rank that skipped them would leave rank 0 waiting in RCCL forever); only rank 0
-        # instruments its launches and reports.
-        if rank == 0:
-            eng.profile_enable(True)
-        nprof = 2
-        for _ in range(nprof):
-            tr.step(non, ocl, label)
-        fence()
-    if rank == 0 and not args.no_roofline:
-        st = eng.profile_read()
-        eng.profile_enable(False)
-        sha = so_sha256()
-        cls = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches_per_step': v['launches'] // nprof,
-                   'executed_tflops': round(v['flops_executed'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] and v['flops_executed'] else None}
-               for k, v in st.items() if v['launches']}
-        dom = st['wino_fused']
-        dom_s = dom['ms'] * 1e-3
-        dom_tf = dom['flops_executed'] / dom_s / 1e12 if dom['ms'] else 0.0
-        dom_useful_tf = dom['flops_useful'] / dom_s / 1e12 if dom['ms'] else 0.0
-        mf = [st[k] for k in ('wino_fused', 'conv_igemm', 'wgrad')]
-        mf_ms = sum(v['ms'] for v in mf)
-        mf_tf = sum(v['flops_executed'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
-        mf_useful_tf = sum(v['flops_useful'] for v in mf) / (mf_ms * 1e-3) / 1e12 if mf_ms else 0.0
-        tot_ms = sum(v['ms'] for v in st.values()) / nprof
-        tr_pmc = pmc_traffic(sha, batch=B, live=False, workload='train')
-        roof = {'bound': 'mfma', 'kernel': 'k_wino_fused (frozen encoder + RecNet forward + data gradients)',
-                'achieved': round(dom_tf, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                'frac_useful': round(dom_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                'traffic': tr_pmc.get('hbm_bytes_per_launch'), 'traffic_detail': tr_pmc,
-                'avg_launch_us': round(dom['ms'] * 1e3 / max(1, dom['launches']), 2),
-                'mfma_kernels': {'kernels': 'k_wino_fused + k_igemm/k_gemm_stream + k_wgrad', 'executed_tflops': round(mf_tf, 2),
-                                 'frac': round(mf_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 'frac_useful': round(mf_useful_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 'ms_per_step': round(mf_ms / nprof, 3)},
-                'hbm_kernels_ms_per_step': round(tot_ms - mf_ms / nprof, 3),
-                'all_kernels_ms_per_step': round(tot_ms, 3),
-                'per_class': cls,
-                'note': 'every launch of the iteration is instrumented (hipEvent pairs on the launch stream): the inference-path '
-                        'classes (encoder), wgrad, and train_bn (BatchNorm statistics / apply / backward), train_loss (loss items, '
-                        'CosFace head), train_optim (zero_grad, clip + Adam), train_xform (Winograd weight / gradient transforms, '
-                        'dgrad packing, reflection folds), train_elem (remaining elementwise / layout kernels); the classes add up '
-                        'to all_kernels_ms_per_step, which contains the dispatch gaps and is slightly more than ms_per_step'}
+        # tr.step() contains the gradient all-reduce, a COLLECTIVE: every rank runs the profiled iterations (a rank that
+        # skipped them would leave rank 0 waiting in RCCL forever); only rank 0 instruments its launches and reports.
+        roof = train_roofline(eng, lambda: tr.step(non, ocl, label), B, fence, instrument=(rank == 0))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_train()
@@ -500,8 +543,10 @@ def main():
     eng = ffrnet_amd.Engine(local)
     for kv in args.opt:
         eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+    t_load = time.perf_counter()
     eng.load_encoder(sd_e)
     eng.load_recnet(sd_r)
+    t_load = time.perf_counter() - t_load
     strong = args.pairs_per_step > 0
     if strong:
         if (2 * args.pairs_per_step) % world:
@@ -509,7 +554,9 @@ def main():
         B = 2 * args.pairs_per_step // world
     else:
         B = args.batch
-    eng.reserve(max(B, 8))
+    t_res = time.perf_counter()
+    eng.reserve(max(B, 8))           # workspace arena + (first time a batch can use them) the exact-tiling weight sets, derived on the device
+    t_res = time.perf_counter() - t_res
 
     # ---- parity gate: the reference's own outputs for the 8 images of golden G1 (tests/golden/make_golden.py) ----
     g1 = np.load(os.path.join(ROOT, 'tests', 'golden', 'g1_config1.npz'))
@@ -615,6 +662,9 @@ def main():
         compulsory_gb = sum(v['bytes'] for v in st.values()) / nprof / 1e9
         alg_tf = value / world * GFLOP_PER_IMAGE / 1e3          # embeddings/s x 15.1427 GFLOP
         tr = pmc_traffic(sha, batch=B, live=(world == 1))   # child profiler passes only when no other rank waits on this one
+        # SURVEY 8(d)'s denominator: ~56 MB of fused activation traffic per image (14.3 GB at batch 256) + 273.2 MB of weights per forward
+        survey_gb = 14.3 * B / 256.0 + 0.2732
+        ratio_survey = round(tr['hbm_gb_per_step_all_kernels'] / survey_gb, 3) if tr.get('hbm_gb_per_step_all_kernels') else None
         ratio = round(tr['hbm_gb_per_step_all_kernels'] / compulsory_gb, 3) if tr.get('hbm_gb_per_step_all_kernels') else None
         if ratio:
             # VERDICT r03 divided the all-kernel PMC bytes by the compulsory bytes of the HBM-bound classes alone (3.0 x);
@@ -637,7 +687,11 @@ def main():
                 'frac_useful_f4x4_equivalent': round(dom['flops'] / 4.0 / dom_s / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 'frac_algorithmic_survey_8d': round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),  # whole step, direct-convolution count
                 'traffic': tr.get('hbm_bytes_per_launch'),              # HBM bytes per launch of the dominant kernel (PMC), or null
-                'traffic_ratio_vs_compulsory': ratio,                   # all kernels: PMC bytes per step / compulsory bytes per step
+                # all kernels: PMC bytes per step / SURVEY 8(d)'s algorithmic bytes (56 MB per image + the weights once): the wasted-re-read figure
+                'traffic_ratio_vs_compulsory': ratio_survey,
+                'traffic_compulsory_gb_survey_8d': round(survey_gb, 3),
+                # ... / the sum of every launch's own operands (a V tensor counts for the kernel that writes it AND the one that reads it)
+                'traffic_ratio_vs_per_launch_operands': ratio,
                 'note': 'frac: FLOPs the matrix cores EXECUTED in the fused Winograd launches (2*xi*ceil(T/32)*32*cin_pad*cout_pad per '
                         'launch and tile type, xi = 36, or 36/32/32/28 for the four tile types of a 14x14 map) / their hipEvent '
                         'time / peak.  frac_useful: the same without padding (tiles hanging over 7x7 maps, padded xi, rows beyond T, '
@@ -684,6 +738,19 @@ def main():
                 'all_kernels_ms_per_step': round(tot_ms / nprof, 3),
                 'so_sha256': sha}
 
+    # load / pack seconds and device bytes of the handle: wall clock of ffr_load_encoder + ffr_load_recnet (host-side
+    # BN folding, Winograd weight transforms, fragment orders; torch.set_num_threads above does not matter: the packer is one
+    # thread) and of the first ffr_reserve, and what the handle holds afterwards
+    ms_ = eng.memory_stats()
+    load = {'load_s': round(t_load, 3), 'reserve_s': round(t_res, 3),
+            'encoder_load_s': round(ms_['encoder_load_seconds'], 3), 'recnet_load_s': round(ms_['recnet_load_seconds'], 3),
+            'mixed_tile_pack_s': round(ms_['mixed_tile_pack_seconds'], 4),
+            'weight_gb': round((ms_['encoder_weight_bytes'] + ms_['recnet_weight_bytes']) / 1e9, 3),
+            'mixed_tile_weight_gb': round(ms_['mixed_tile_weight_bytes'] / 1e9, 3),
+            'workspace_gb': round(ms_['workspace_bytes'] / 1e9, 3),
+            'note': 'mixed_tile_*: the three extra Winograd weight sets of the exact 14x14 tiling, derived on the device at the first '
+                    'reserve / forward of a batch that uses them (>= 128 images), 0 for handles that only see smaller batches'}
+
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not strong:
         # configs[1]: backbone only (featmap + f); and the 112x96 of the metric label, which exists for the trunk only
@@ -699,6 +766,7 @@ def main():
              'value': round(B / ms96['median'] * 1e3, 1), 'unit': 'images/s', 'ms': ms96,
              'effective_tflops_algorithmic': round(B * GFLOP_TRUNK_96 / ms96['median'], 2)}]
         secondary.append(lfw_protocol_line(eng, dev))
+        secondary.append(train_step_line(eng, sd_r, dev))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -721,7 +789,7 @@ def main():
                           'parallelism': 'image-sharded x%d, RCCL all-gather of embeddings' % world},
                'step_ms_hipevents': step_ms, 'per_rank': per_rank, 'options': args.opt or None,
                'parity_checked': {'max_rel_err_vs_reference_golden_G1': parity, 'tolerance': PARITY_TOL},
-               'roofline': roof, 'cpu_baseline': cpu, 'secondary': secondary}
+               'load': load, 'roofline': roof, 'cpu_baseline': cpu, 'secondary': secondary}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

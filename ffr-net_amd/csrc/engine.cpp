@@ -48,6 +48,8 @@ int upload(ffr_handle* h, std::vector<void*>& owner, const std::vector<float>& v
     if (hipMalloc(&p, v.size() * sizeof(float)) != hipSuccess)
         return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu weight bytes failed", v.size() * sizeof(float));
     owner.push_back(p);
+    if (h && &owner == &h->enc_allocs) h->enc_weight_bytes += v.size() * sizeof(float);
+    if (h && &owner == &h->rec_allocs) h->rec_weight_bytes += v.size() * sizeof(float);
     HIPCK(h, hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = (float*)p;
     return FFR_OK;
@@ -105,7 +107,6 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
     RC(upload(h, owner, bias, &L->bias));
     L->wu = nullptr;
     L->wuc = nullptr;
-    L->wuq = nullptr;
     for (int tau = 0; tau < 4; ++tau) L->wum[tau] = nullptr;
     const int wino_min_cin = h->opt.wino_mincin;
     if (R == 3 && S == 3 && stride == 1 && pad == 1 && L->cin_pad >= wino_min_cin && wino_min_cin > 0) {
@@ -144,57 +145,6 @@ int pack_conv(ffr_handle* h, std::vector<void*>& owner, const float* W, int cout
                             for (int e = 0; e < 4; ++e) dst[e] = src[e];
                         }
         RC(upload(h, owner, wuc, &L->wuc));
-        // ... for the tile types (4,3), (3,4), (3,3) of the exact 4+4+3+3 tiling of 14x14 maps (wino_mixed.hip): U = G_r g G_c^T with
-        // the 5-point F(3,3) matrix for a 3-output dimension; xi padded to 32 / 32 / 28 with zeros
-        if (L->cin_pad == 256 && pad_mode == 0 && h->opt.wf_mixed) {
-            static const double G3[5][3] = {{0.5, 0, 0}, {-0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0, 0, 1}};
-            L->wum[0] = L->wuc;
-            for (int tau = 1; tau < 4; ++tau) {
-                const int mr = tau >= 2 ? 3 : 4, mc = (tau & 1) ? 3 : 4, ar = mr + 2, ac = mc + 2;
-                const int xp = wino_mixed_xp(tau);
-                std::vector<float> um((size_t)nbn * nkc * xp * 512, 0.f);
-                for (int co = 0; co < cout; ++co) {
-                    const double g = out_bn ? out_bn->s[co] : 1.0;
-                    const int nb = co / 64, nl = co % 64;
-                    for (int ci = 0; ci < cin; ++ci) {
-                        const float* gk = W + ((size_t)co * cin + ci) * 9;
-                        const double sc = (in_bn ? in_bn->s[ci] : 1.0) * g;
-                        double tmp[6][3];
-                        for (int i = 0; i < ar; ++i)
-                            for (int c = 0; c < 3; ++c) {
-                                const double* gr = mr == 4 ? G[i] : G3[i];
-                                tmp[i][c] = gr[0] * gk[0 * 3 + c] + gr[1] * gk[1 * 3 + c] + gr[2] * gk[2 * 3 + c];
-                            }
-                        const int kc = ci / 8, hf = (ci % 8) / 4, e4 = ci % 4;
-                        const int piece = (nl >> 5) * 64 + hf * 32 + (nl & 31);
-                        for (int i = 0; i < ar; ++i)
-                            for (int j = 0; j < ac; ++j) {
-                                const double* gc = mc == 4 ? G[j] : G3[j];
-                                const double u = tmp[i][0] * gc[0] + tmp[i][1] * gc[1] + tmp[i][2] * gc[2];
-                                um[((((size_t)nb * nkc + kc) * xp + (i * ac + j)) * 128 + piece) * 4 + e4] = (float)(u * sc);
-                            }
-                    }
-                }
-                RC(upload(h, owner, um, &L->wum[tau]));
-            }
-        }
-        // ... and in the order k_wino_fused_q streams them (wino_fused_q.hip): per 64-channel group and 16-channel K slice
-        // (dq), per xi, one 1 KB fragment per wave (a wave's fragments are contiguous: [nb][wave][dq][xi]): lane = 16 * (k group) + (output channel & 15) of the wave's 16 channels,
-        // the lane's four floats = k 16 dq + 4 (k group) + 0..3
-        if (L->cin_pad <= h->opt.wf_phased_maxk && L->cin_pad % 32 == 0) {
-            const int ndq = L->cin_pad / 16;
-            std::vector<float> wuq(wu.size());
-            for (int nb = 0; nb < nbn; ++nb)
-                for (int wv = 0; wv < 4; ++wv)
-                    for (int dq = 0; dq < ndq; ++dq)
-                        for (int xi = 0; xi < 36; ++xi)
-                            for (int ln = 0; ln < 64; ++ln) {
-                                float* dst = &wuq[(((((size_t)nb * 4 + wv) * ndq + dq) * 36 + xi) * 64 + ln) * 4];
-                                const float* src = &wu[((size_t)xi * L->cout_pad + nb * 64 + 16 * wv + (ln & 15)) * L->cin_pad + 16 * dq + 4 * (ln >> 4)];
-                                for (int e = 0; e < 4; ++e) dst[e] = src[e];
-                            }
-            RC(upload(h, owner, wuq, &L->wuq));
-        }
     }
     L->slope = nullptr;
     if (slope) {
@@ -260,17 +210,62 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
     return half_n ? 2 : 1;
 }
 
-// True when the convolution runs on the exact 4+4+3+3 tiling (k_wino_fused_mixed): 14x14 map, zero padding, the three extra
-// weight sets packed, scratch large enough, and every CU gets at least two blocks -- the gain comes from pairing a long block
-// with a short one on a CU; with one block per CU the (4,4) blocks set the time and nothing is won.
-// wino_mode 4 forces it (tests).
-bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
-    if (!L.wum[1] || L.pad_mode != 0 || H != 14 || W != 14 || in_pitch != L.cin_pad) return false;
+// True when the convolution WOULD run on the exact 4+4+3+3 tiling (k_wino_fused_mixed) once the three extra weight sets exist:
+// 14x14 map, zero padding, scratch large enough, and every CU gets at least one block.
+// wino_mode 4 forces it (tests, experiments; 7x7 maps = 4+3 too).
+bool wino_mixed_eligible(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
+    if (!L.wuc || !L.w || L.R != 3 || L.S != 3 || L.stride != 1 || L.pad_mode != 0 || in_pitch != L.cin_pad) return false;
+    if (!(H == 14 && W == 14) && !(wino_mode == 4 && H == 7 && W == 7)) return false;
     WinoMixedGeom g;
     if (!wino_mixed_geom(H, W, &g) || wino_mixed_v_floats(g, N, L.cin_pad, nullptr) > wino_cap) return false;
     if (wino_mode == 4) return true;
     if (wino_mode >= 0 || !h->opt.wino || !h->opt.wino_fused || !h->opt.wf_mixed) return false;
-    return wino_mixed_blocks(N, H, W, L.cout_pad) >= 2 * h->num_cus;
+    // >= 2 blocks per CU: a long block pairs with a short one (16 instead of 18 slots per CU).  With ONE block per CU the (4,4) blocks
+    // set the time and the fused kernel gains nothing, but the launch still wins 10 % because V is 16 % smaller and its transform
+    // cheaper (round 5, tools/mixed7_experiment.py: 256 -> 256 at 128 images: 94.4 + 39.4 us padded vs 92.7 + 28.4 us exact)
+    return wino_mixed_blocks(N, H, W, L.cout_pad) >= h->num_cus;
+}
+// ... and does: the weight sets are there (prepare_mixed_weights ran for this layer)
+bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
+    return L.wum[1] && wino_mixed_eligible(h, L, N, H, W, in_pitch, wino_cap, wino_mode);
+}
+
+// The weights of the tile types (4,3), (3,4), (3,3) of one layer, derived ON THE DEVICE from its packed direct weights the first
+// time a launch is eligible (round 4 packed them on the host at load time for all 27 layers, 0.7 GB per handle, whether or not
+// a batch of >= 256 images ever arrived).  Synchronous (hipMalloc + three small kernels); never inside a stream capture: the
+// callers run it from ensure_arena / before the launch of an operator test.
+int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner) {
+    if (L.wum[1]) return FFR_OK;
+    if (!L.wuc || !L.w) return fail(h, FFR_ERR_STATE, "mixed-tile weights asked for a layer without Winograd weights");
+    float* um[4] = {L.wuc, nullptr, nullptr, nullptr};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int tau = 1; tau < 4; ++tau) {
+        void* p = nullptr;
+        const size_t bytes = wino_mixed_u_floats(tau, L.cout_pad, L.cin_pad) * sizeof(float);
+        if (hipMalloc(&p, bytes) != hipSuccess) return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu mixed-tile weight bytes failed", bytes);
+        owner.push_back(p);
+        um[tau] = (float*)p;
+        HIPCK(h, launch_wino_weights_mixed(L.w, um[tau], L.cout_pad, L.cin_pad, tau, nullptr));
+        if (&owner == &h->enc_allocs) { h->mixed_weight_bytes += bytes; h->enc_weight_bytes += bytes; }
+    }
+    HIPCK(h, hipDeviceSynchronize());
+    h->mixed_pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int tau = 0; tau < 4; ++tau) L.wum[tau] = um[tau];
+    return FFR_OK;
+}
+
+// Every encoder convolution that a forward of N images of H x W would run on the exact tiling gets its weight sets now.
+int prepare_mixed_weights(ffr_handle* h, int N, int H, int W, size_t wino_cap) {
+    if (!h->enc_loaded || !h->opt.wf_mixed || !h->opt.wino || !h->opt.wino_fused) return FFR_OK;
+    if (h->mixed_ready_n >= N && h->mixed_ready_h == H && h->mixed_ready_w == W) return FFR_OK;     // the common case: one comparison per forward
+    int ch = H, cw = W;
+    for (Block& b : h->blocks) {
+        if (wino_mixed_eligible(h, b.c1, N, ch, cw, b.cin, wino_cap, -1)) RC(ensure_mixed_weights(h, b.c1, h->enc_allocs));
+        if (b.stride == 1 && wino_mixed_eligible(h, b.c2, N, ch, cw, b.depth, wino_cap, -1)) RC(ensure_mixed_weights(h, b.c2, h->enc_allocs));
+        ch /= b.stride; cw /= b.stride;
+    }
+    h->mixed_ready_n = N; h->mixed_ready_h = H; h->mixed_ready_w = W;
+    return FFR_OK;
 }
 
 // True when the Winograd convolution (L on N x H x W) will run k_wino_fused over the WHOLE batch from a V that already
@@ -348,6 +343,14 @@ int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, doubl
     int tile, nblocks;
     int force = c.tile;
     if (!force && a.cout_pad == 64 && a.nbatch == 1 && a.M >= 65536 && a.nkt >= 9) force = h->opt.igemm_tile64;   // A/B knob
+    if (force) {      // a forced tile whose width does not divide cout_pad would launch zero column tiles and leave `out` unwritten
+        int fbm, fbn;
+        igemm_tile_shape(force, &fbm, &fbn);
+        if (a.cout_pad % fbn) {
+            if (c.tile) return fail(h, FFR_ERR_ARG, "conv: forced tile %d (%d x %d) does not divide cout_pad %d", force, fbm, fbn, a.cout_pad);
+            force = 0;      // the igemm_tile64 knob: ignored where it does not fit
+        }
+    }
     plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, force, h->opt.sk_minunits, &tile, &nblocks, &a.granule);
     int bm, bn;
     igemm_tile_shape(tile, &bm, &bn);
@@ -441,6 +444,78 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             fexec += 2.0 * wino_mixed_xp(tau) * std::ceil(Tt / 32.0) * 32.0 * L.cout_pad * L.cin_pad;
             fuse += 2.0 * wino_mixed_x(tau) * Tt * L.cout * L.cin;
         }
+#ifdef FFR_TRACE
+        if (h->opt.wf_trace) {      // diagnostics: per-block phase stamps and which CU ran which tile types, printed after a stream sync
+            const int nbm = wino_mixed_blocks_launched(c.N, c.H, c.W, L.cout_pad);
+            unsigned long long* dbuf = nullptr;
+            HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nbm * 12 * sizeof(unsigned long long)));
+            HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nbm * 12 * sizeof(unsigned long long), st));
+            f.trace = dbuf;
+            hipEvent_t e0, e1;
+            HIPCK(h, hipEventCreate(&e0)); HIPCK(h, hipEventCreate(&e1));
+            HIPCK(h, hipEventRecord(e0, st));
+            HIPCK(h, launch_wino_fused_mixed(f, st));
+            HIPCK(h, hipEventRecord(e1, st));
+            HIPCK(h, hipStreamSynchronize(st));
+            float ev_ms = 0.f;
+            HIPCK(h, hipEventElapsedTime(&ev_ms, e0, e1));
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            std::vector<unsigned long long> tr((size_t)nbm * 12);
+            HIPCK(h, hipMemcpy(tr.data(), dbuf, tr.size() * 8, hipMemcpyDeviceToHost));
+            HIPCK(h, hipFree(dbuf));
+            double pro[4] = {0, 0, 0, 0}, loop[4] = {0, 0, 0, 0}, ep1[4] = {0, 0, 0, 0}, ep2[4] = {0, 0, 0, 0}, clk[4] = {0, 0, 0, 0};
+            int cnt[4] = {0, 0, 0, 0};
+            unsigned long long r_first = ~0ull, r_last = 0;
+            struct Run { unsigned long long start, end; int tau; };
+            std::map<unsigned long long, std::vector<Run>> per_cu;
+            for (int b = 0; b < nbm; ++b) {
+                const unsigned long long* q = &tr[(size_t)b * 12];
+                if (!q[9]) continue;
+                const int tau = (int)q[8];
+                pro[tau] += (double)(q[1] - q[0]); loop[tau] += (double)(q[2] - q[1]); ep1[tau] += (double)(q[3] - q[2]); ep2[tau] += (double)(q[4] - q[3]);
+                clk[tau] += (double)(q[4] - q[0]) / (double)(q[6] - q[5]) * 0.1;       // shader cycles per 10 ns tick -> GHz
+                ++cnt[tau];
+                if (q[5] < r_first) r_first = q[5];
+                if (q[6] > r_last) r_last = q[6];
+                per_cu[q[7]].push_back(Run{q[5], q[6], tau});
+            }
+            static const char* tname[4] = {"(4,4)", "(4,3)", "(3,4)", "(3,3)"};
+            fprintf(stderr, "[wf trace] mixed %dx%d cin %d cout %d, %d images: hipEvent %.1f us, first block start to last block end %.1f us\n",
+                    c.H, c.W, L.cin_pad, L.cout_pad, c.N, ev_ms * 1e3, (double)(r_last - r_first) / 100.0);
+            for (int tau = 0; tau < 4; ++tau) {
+                if (!cnt[tau]) continue;
+                const int S = wino_mixed_xp(tau) / 4;
+                fprintf(stderr, "[wf trace]   type %s: %d blocks of %d slots | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk, floor %d) "
+                                "epilogue %.0f + %.0f = block %.0f cyc at %.2f GHz = %.1f us\n", tname[tau], cnt[tau], S, pro[tau] / cnt[tau], loop[tau] / cnt[tau],
+                        loop[tau] / cnt[tau] / f.nkc, S * 8 * 64, ep1[tau] / cnt[tau], ep2[tau] / cnt[tau],
+                        (pro[tau] + loop[tau] + ep1[tau] + ep2[tau]) / cnt[tau], clk[tau] / cnt[tau],
+                        (pro[tau] + loop[tau] + ep1[tau] + ep2[tau]) / cnt[tau] / (clk[tau] / cnt[tau]) * 1e-3);
+            }
+            // which block types did each CU run, in order; how long was it busy, how long idle between / after its blocks
+            std::map<std::string, int> hist;
+            double busy = 0, gap = 0, tail = 0, lead = 0;
+            for (auto& kv : per_cu) {
+                auto& v = kv.second;
+                std::sort(v.begin(), v.end(), [](const Run& x, const Run& y) { return x.start < y.start; });
+                std::string key;
+                for (size_t i = 0; i < v.size(); ++i) {
+                    key += tname[v[i].tau];
+                    busy += (double)(v[i].end - v[i].start);
+                    if (i) gap += (double)(v[i].start - v[i - 1].end);
+                }
+                lead += (double)(v.front().start - r_first);
+                tail += (double)(r_last - v.back().end);
+                ++hist[key];
+            }
+            const double ncu = (double)per_cu.size();
+            fprintf(stderr, "[wf trace]   %d CUs ran blocks; per CU: busy %.1f us, idle before its first block %.1f, between blocks %.1f, after its last block %.1f us | sequences:",
+                    (int)per_cu.size(), busy / ncu / 100.0, lead / ncu / 100.0, gap / ncu / 100.0, tail / ncu / 100.0);
+            for (auto& kv : hist) fprintf(stderr, "  %s x %d", kv.first.c_str(), kv.second);
+            fprintf(stderr, "\n");
+            if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
+            return FFR_OK;
+        }
+#endif
         Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec, fuse);
         HIPCK(h, launch_wino_fused_mixed(f, st));
         if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
@@ -530,10 +605,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                 HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nb * 40 * sizeof(unsigned long long)));
                 HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nb * 40 * sizeof(unsigned long long), st));
                 f.trace = dbuf;
-                f.Uq = (phased && h->opt.wf_q) ? L.wuq : nullptr;
-                const bool qform = wino_fused_q_ok(f);
-                if (qform) HIPCK(h, launch_wino_fused_q(f, st));
-                else HIPCK(h, launch_wino_fused(f, st));
+                HIPCK(h, launch_wino_fused(f, st));
                 HIPCK(h, hipStreamSynchronize(st));
                 std::vector<unsigned long long> tr((size_t)nb * 40);
                 HIPCK(h, hipMemcpy(tr.data(), dbuf, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -553,12 +625,9 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                     const int cpp = 4, nph = f.nkc / cpp;                      // K chunks per phase, phases
                     fprintf(stderr, "[wf trace] %dx%d cin %d cout %d (input transform in the kernel, %d-channel blocks%s): %d live blocks of %d | per block (wave 0): "
                                     "prologue %.0f loop %.0f = %d phases x (transform %.0f + barrier %.0f + %d K chunks of %.0f) epilogue %.0f cyc | "
-                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, half_n ? 32 : 64, qform ? ", q form: all xi per wave" : "", cnt, nb,
+                                    "block ends spread over %.1f us\n", c.H, c.W, L.cin_pad, L.cout_pad, half_n ? 32 : 64, "", cnt, nb,
                             pro / cnt, loop / cnt, nph, ep[0] / cnt, ep[1] / cnt, cpp, (loop / cnt / nph - ep[0] / cnt - ep[1] / cnt) / cpp, epi / cnt,
                             (double)(r1 - r0) / 100.0);
-                    if (qform) fprintf(stderr, "[wf trace]    q-form epilogue: tiles 0-15 (register transform + activation + to LDS) %.0f, barrier + tiles 16-31 with the stores of "
-                                               "tiles 0-15 underneath %.0f, barrier + stores of tiles 16-31 %.0f cyc\n",
-                                       ep[2] / cnt, ep[3] / cnt, (epi - ep[2] - ep[3]) / cnt);
                 }
                 else
                     fprintf(stderr, "[wf trace] %dx%d cin %d cout %d: %d live blocks of %d | per block (wave 0): prologue %.0f loop %.0f (%.0f per K chunk) "
@@ -570,9 +639,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             }
 #endif
             Scope s(h, st, FFR_KC_WINO_FUSED, flops, bytes, fexec, flops / 4.0);
-            f.Uq = (phased && h->opt.wf_q) ? L.wuq : nullptr;
-            if (wino_fused_q_ok(f)) HIPCK(h, launch_wino_fused_q(f, st));
-            else HIPCK(h, launch_wino_fused(f, st));
+            HIPCK(h, launch_wino_fused(f, st));
             if (c.tile_sums && c.tile_sums_written) *c.tile_sums_written = true;
             return FFR_OK;
         }
@@ -734,7 +801,7 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
     *w = layout(h->opt, h->arena, N, H, W);
     w->tickets = h->tickets;
     w->tickets_cap = h->tickets_cap;
-    return FFR_OK;
+    return prepare_mixed_weights(h, N, H, W, w->wino_cap);
 }
 
 // ---- encoder ---------------------------------------------------------------------------
@@ -885,7 +952,8 @@ int run_recnet(ffr_handle* h, const Work& w, int N, float* f_new, const RecDebug
         // ss_channel Gram + Conv4Channel (6 linears) + M_channel @ X, algorithmic (unfused) count
         const double fl = 2.0 * N * (512.0 * 512 * 49 + 512.0 * (561 * 32 + 5 * 32 * 512) + 512.0 * 512 * 49);
         Scope s(h, st, FFR_KC_CHANNEL, fl, 4.0 * N * (49 * 512 * 3));
-        HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st, dbg ? dbg->ss_channel0 : nullptr, dbg ? dbg->M_channel0 : nullptr));
+        HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st, dbg ? dbg->ss_channel0 : nullptr, dbg ? dbg->M_channel0 : nullptr, h->num_cus,
+                                     h->opt.channel_rows));
     }
     // Conv4Space (recnet.py:362-371)
     RC(conv_rec(h, w, h->sp[0], w.bufS, 576, nullptr, 0, w.s256a, 256, 0, 0, N, st));
@@ -973,7 +1041,6 @@ int ffr_create(ffr_handle** out, int device) {
     hipError_t e = igemm_init();
     if (e == hipSuccess) e = gemm_stream_init();
     if (e == hipSuccess) e = wino_fused_init();
-    if (e == hipSuccess) e = wino_fused_q_init();
     if (e == hipSuccess) e = wino_mixed_init();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
@@ -1014,6 +1081,8 @@ int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
     free_list(h->enc_allocs);
     ++h->generation;
     h->enc_loaded = false;
+    h->mixed_ready_n = 0; h->mixed_weight_bytes = 0; h->enc_weight_bytes = 0; h->mixed_pack_s = 0.0;
+    const auto load_t0 = std::chrono::steady_clock::now();
     SD sd; sd.h = h;
     for (int i = 0; i < n; ++i) if (t[i].name) sd.m[t[i].name] = &t[i];
     auto& own = h->enc_allocs;
@@ -1102,6 +1171,7 @@ int ffr_load_encoder(ffr_handle* h, const ffr_tensor_desc* t, int n) {
         RC(upload(h, own, bb, &L.bias));
     }
     h->enc_loaded = true;
+    h->enc_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - load_t0).count();
     return FFR_OK;
 }
 
@@ -1112,6 +1182,8 @@ int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n) {
     free_list(h->rec_allocs);
     ++h->generation;
     h->rec_loaded = false;
+    h->rec_weight_bytes = 0;
+    const auto load_t0 = std::chrono::steady_clock::now();
     SD sd; sd.h = h;
     for (int i = 0; i < n; ++i) if (t[i].name) sd.m[t[i].name] = &t[i];
     auto& own = h->rec_allocs;
@@ -1206,6 +1278,19 @@ int ffr_load_recnet(ffr_handle* h, const ffr_tensor_desc* t, int n) {
         RC(upload(h, own, b8a, &p)); cw.b8a = p;
     }
     h->rec_loaded = true;
+    h->rec_load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - load_t0).count();
+    return FFR_OK;
+}
+
+int ffr_memory_stats(const ffr_handle* h, ffr_mem_stats* out) {
+    if (!h || !out) return fail(nullptr, FFR_ERR_ARG, "ffr_memory_stats: null argument");
+    out->encoder_weight_bytes = h->enc_weight_bytes;
+    out->recnet_weight_bytes = h->rec_weight_bytes;
+    out->mixed_tile_weight_bytes = h->mixed_weight_bytes;
+    out->workspace_bytes = h->arena_bytes;
+    out->encoder_load_seconds = h->enc_load_s;
+    out->recnet_load_seconds = h->rec_load_s;
+    out->mixed_tile_pack_seconds = h->mixed_pack_s;
     return FFR_OK;
 }
 
@@ -1312,7 +1397,8 @@ const OptEntry OPTIONS[] = {
     {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
     {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
     {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1},
-    {"wf_q", &Options::wf_q, nullptr, 0, 1}, {"wf_mixed", &Options::wf_mixed, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
+    {"wf_mixed", &Options::wf_mixed, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
+    {"channel_rows", &Options::channel_rows, nullptr, 0, 4},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {
@@ -1326,6 +1412,7 @@ int ffr_set_option(ffr_handle* h, const char* name, long long value) {
     const OptEntry* e = find_option(name);
     if (!e) return fail(h, FFR_ERR_ARG, "ffr_set_option: unknown option '%s'", name ? name : "(null)");
     if (value < e->lo || value > e->hi) return fail(h, FFR_ERR_ARG, "ffr_set_option: %s = %lld is outside [%lld, %lld]", name, value, e->lo, e->hi);
+    if (e->i == &Options::channel_rows && value == 3) return fail(h, FFR_ERR_ARG, "ffr_set_option: channel_rows is 0 (auto), 1, 2 or 4");
 #ifndef FFR_TRACE
     if ((e->i == &Options::wf_trace || e->i == &Options::igemm_trace) && value)
         return fail(h, FFR_ERR_UNSUPPORTED, "ffr_set_option: %s needs a -DFFR_TRACE build of the library (tools/trace_build.py)", name);
@@ -1448,6 +1535,10 @@ int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, 
     ConvW L;
     int rc = pack_conv(h, own, w_host, cout, cin, 3, 3, nullptr, &ob, slope_host, 1, 1, pad_mode, &L);
     if (rc == FFR_OK && use_wino && !L.wu) rc = fail(h, FFR_ERR_UNSUPPORTED, "layer not eligible for the Winograd path (cin < FFR_WINO_MINCIN)");
+    if (rc == FFR_OK && use_wino == 4) {
+        if (!wino_mixed_eligible(h, L, N, H, W, cin, w.wino_cap, 4)) rc = fail(h, FFR_ERR_UNSUPPORTED, "layer / map not eligible for the mixed-tile path");
+        else rc = ensure_mixed_weights(h, L, own);
+    }
     if (rc == FFR_OK) {
         ConvCall c{};
         c.x = x; c.N = N; c.H = H; c.W = W; c.in_pitch = cin; c.resid = resid; c.res_pitch = cout;

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -29,10 +31,9 @@ struct ConvW {
     float* bias = nullptr;
     float* slope = nullptr;
     float* wu = nullptr;     // Winograd F(4,3) weights [36][cout_pad][cin_pad] (G g G^T, BN folded) or null
-    float* wuq = nullptr;    // the same in the per-wave order of k_wino_fused_q ([cout_pad/64][4 waves][cin_pad/16][36][64 lanes][4]) for
-                             // layers that transform their own input (cin_pad <= wf_phased_maxk at load time), or null
     float* wum[4] = {nullptr, nullptr, nullptr, nullptr};   // mixed tile sizes (wino_mixed.hip): weights of the tile types (4,3), (3,4), (3,3) in fragment
-                             // order at [1..3] ([0] = wuc), for zero-padded layers with cin_pad == 256 (the 14x14 maps of stage 3), or null
+                             // order at [1..3] ([0] = wuc); derived on the device from `w` the first time a launch of this layer is eligible
+                             // (engine.cpp, ensure_mixed_weights), null before
     float* wuc = nullptr;    // the same in the K-chunk order k_wino_fused streams ([cout_pad/64][cin_pad/8][36][128][4]) or null
 };
 
@@ -64,7 +65,7 @@ struct Options {
     int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
     int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
     int wf_mixed = 1;             // 1: 14x14 maps are tiled 4+4+3+3 (k_wino_fused_mixed) when the launch gives every CU two blocks or more
-    int wf_q = 0;                 // 1: the phased fused launches (in-kernel input transform) run k_wino_fused_q (round-4 experiment: a tie)
+    int channel_rows = 0;         // k_channel_path: blocks per image (1, 2, 4); 0 = from the batch and the CU count (round 5)
     int igemm_tile64 = 0;         // > 0: tile shape forced for large direct convolutions with 64 output channels (1..4, ffr_conv_desc.tile)
     int combine_v = 1;            // 1: a bottleneck's combine also writes V for the next conv1 when that runs k_wino_fused from V
     int wf_trace = 0, igemm_trace = 0;   // -DFFR_TRACE builds only: per-launch phase stamps on stderr (synchronises)
@@ -89,6 +90,10 @@ struct ffr_handle {
     // weights
     std::vector<void*> enc_allocs, rec_allocs;
     bool enc_loaded = false, rec_loaded = false;
+    size_t enc_weight_bytes = 0, rec_weight_bytes = 0;      // device bytes of the packed weights (ffr_memory_stats)
+    size_t mixed_weight_bytes = 0;                          // of them: the lazily derived weight sets of the exact 14x14 tiling
+    double enc_load_s = 0.0, rec_load_s = 0.0, mixed_pack_s = 0.0;   // wall seconds of the last ffr_load_* / of all lazy packs
+    int mixed_ready_n = 0, mixed_ready_h = 0, mixed_ready_w = 0;     // prepare_mixed_weights ran for batches up to n of h x w
     float *stem_w = nullptr, *stem_b = nullptr, *stem_s = nullptr;
     std::vector<ffr_eng::Block> blocks;      // 24 / 49 / 50 bottlenecks: Backbone(50 | 100 | 152), with or without SE
     float *bn_s = nullptr, *bn_t = nullptr;
@@ -213,6 +218,9 @@ struct ConvCall {
 int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long T, double x_bytes, int wino_mode);
 bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap);
 bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode);
+bool wino_mixed_eligible(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode);
+int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner);
+int prepare_mixed_weights(ffr_handle* h, int N, int H, int W, size_t wino_cap);
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse = -1.0);
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st);
 

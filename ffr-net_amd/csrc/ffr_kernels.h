@@ -82,7 +82,6 @@ hipError_t launch_wino_in_chunked(const float* x, float* Vc, int N, int H, int W
                                   hipStream_t stream);
 struct WinoFusedArgs {
     const float* Vc; const float* Uc;       // Vc == null: the kernel transforms x itself (phased mode)
-    const float* Uq;                        // phased mode: the weights in the per-wave order of k_wino_fused_q, or null
     const float* x;                         // phased mode: input [N,H,W,in_pitch] ...
     unsigned x_bytes;                       // ... and its size in bytes (<= 1 GiB; out-of-range reads return zeros)
     int in_pitch, pad_mode;
@@ -101,11 +100,6 @@ hipError_t launch_combine_in_c(const float* res, const float* scale, const float
 int wino_fused_blocks(const WinoFusedArgs& a);
 hipError_t wino_fused_init();
 hipError_t launch_wino_fused(WinoFusedArgs a, hipStream_t stream);
-// wino_fused_q.hip: the phased launch in the form where a wave owns all 36 xi of 32 tiles x 16 channels (16x16x4 MFMAs,
-// output transform in registers)
-hipError_t wino_fused_q_init();
-bool wino_fused_q_ok(const WinoFusedArgs& a);
-hipError_t launch_wino_fused_q(WinoFusedArgs a, hipStream_t stream);
 inline size_t wino_chunked_floats(long long T, int cin_pad) { return (size_t)((T + 31) / 32) * 32 * 36 * cin_pad; }
 
 // ---- wino_mixed.hip: exact tilings with tiles of 4 and 3 outputs per dimension (14 = 4+4+3+3, 7 = 4+3) ------------
@@ -127,12 +121,16 @@ struct WinoMixedArgs {
     WinoMixedGeom g;                        // filled by the launcher, as everything below
     int mbn[4], boff[4], nbn, tpi_off[4], tpi_total;
     long long T[4];
+    unsigned long long* trace;              // diagnostics (-DFFR_TRACE build, option "wf_trace"): 12 words per block, or null
 };
 bool wino_mixed_geom(int H, int W, WinoMixedGeom* g);
 int wino_mixed_x(int tau);
 int wino_mixed_xp(int tau);
 size_t wino_mixed_v_floats(const WinoMixedGeom& g, int N, int cin_pad, size_t off[4]);
 int wino_mixed_blocks(int N, int H, int W, int cout_pad);
+size_t wino_mixed_u_floats(int tau, int cout_pad, int cin_pad);
+int wino_mixed_blocks_launched(int N, int H, int W, int cout_pad);
+hipError_t launch_wino_weights_mixed(const float* w, float* um, int cout_pad, int cin_pad, int tau, hipStream_t stream);
 hipError_t wino_mixed_init();
 hipError_t launch_wino_in_mixed(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, hipStream_t stream);
 hipError_t launch_wino_fused_mixed(WinoMixedArgs a, hipStream_t stream);
@@ -206,8 +204,8 @@ struct ChannelPathWeights {   // device pointers, see engine.cpp pack_recnet()
 // feat_channel_raw[c][p] = sum_c' sigmoid(Conv4Channel(..))[c][c'] X[c'][p]; written to
 // bufF[n,p,512+c] and W-flipped to bufF[n,flip(p),c]  (bufF pitch 1024)
 // dbg_ss / dbg_M (parity tests, optional): ss_channel and M_channel [512][512] of image 0, which the path never stores
-hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF,
-                               int N, hipStream_t stream, float* dbg_ss = nullptr, float* dbg_M = nullptr);
+hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF, int N, hipStream_t stream,
+                               float* dbg_ss, float* dbg_M, int num_cus, int row_blocks /* 0 auto | 1 | 2 | 4 blocks per image */);
 // feat_space: out[n,j,c] = sum_i ms[n,j,i] * X[n,i,c]   (ms pitch = ms_pitch, out pitch/coff)
 hipError_t launch_space_apply(const float* X, const float* ms, int ms_pitch, float* out, int out_pitch,
                               int out_coff, int N, hipStream_t stream);

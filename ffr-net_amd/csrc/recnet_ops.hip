@@ -88,7 +88,11 @@ hipError_t launch_selfsim_space(const float* X, float* bufS, int pitchS, float* 
 //   * M_channel rows are produced one column c' at a time and consumed at once by the
 //     running product with X, so M_channel (268 MB) is never stored either.
 // ---------------------------------------------------------------------------------------
+// Round 5: the 512 rows of M_channel are independent (recnet.py:372-386,410), so an image can be cut into 512 / (128 CT) row blocks
+// (grid.y) when there are fewer images than CUs: CT = 32-row tiles per wave = 4 (one block per image, batch >= 256), 2 or 1.  Every
+// row block repeats the transpose and G (P1, P2: 25 of the 245 us a whole image takes) and evaluates only its rows (P3-P6).
 #define XT_LD 52
+template <int CT>
 __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict__ X, const ChannelPathWeights w,
                                                      const float* __restrict__ w1bT, float* __restrict__ bufF,
                                                      int pitchF, float* __restrict__ dbg_ss, float* __restrict__ dbg_M) {
@@ -100,7 +104,9 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
     const float* Xn = X + (size_t)n * 49 * 512;
     const int c0 = tid, c1 = tid + 256;                       // columns this thread transposes in P1
     const int lane = tid & 63, wave = tid >> 6;
-    const int r0 = 128 * wave + lane, r1 = r0 + 64;           // rows whose MLP this thread evaluates (P3, P4)
+    const int row_base = blockIdx.y * (128 * CT) + 32 * CT * wave;      // first row of this wave
+    // rows whose MLP this thread evaluates (P3, P4): CT = 4: two rows per lane; CT = 2: one; CT = 1: lanes 32-63 repeat lanes 0-31
+    const int r0 = row_base + (CT == 1 ? (lane & 31) : lane), r1 = CT == 4 ? r0 + 64 : r0;
 
     {   // P1: transpose into LDS + channel norms
         float s0 = 0.f, s1 = 0.f;
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
         inv[c1] = 1.0f / fmaxf(sqrtf(s1), 1e-12f);
     }
     __syncthreads();
-    if (dbg_ss && n == 0) {     // parity tests only: ss_channel of image 0 from the normalised vectors the path uses
+    if (dbg_ss && n == 0 && blockIdx.y == 0) {     // parity tests only: ss_channel of image 0 from the normalised vectors the path uses
         for (int o = tid; o < 512 * 512; o += 256) {
             const int c = o >> 9, cp = o & 511;
             float s = 0.f;
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
         for (int j = 0; j < 32; ++j) {
             const float wa = w.w1a[j * 49 + p], g = G[p * 32 + j];
             h0[j] += x0 * (wa + i0 * g);
-            h1[j] += x1 * (wa + i1 * g);
+            if constexpr (CT == 4) h1[j] += x1 * (wa + i1 * g);
         }
     }
     // P4: PReLU (slope per row c), two folded 32x32 affines with PReLU after each
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
             h0[j] = h0[j] >= 0.f ? h0[j] : h0[j] * s0;
-            h1[j] = h1[j] >= 0.f ? h1[j] : h1[j] * s1;
+            if constexpr (CT == 4) h1[j] = h1[j] >= 0.f ? h1[j] : h1[j] * s1;
         }
     }
 #pragma unroll 1
@@ -169,38 +175,42 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
             for (int i = 0; i < 32; ++i) {
                 const float a = A[j * 32 + i];
                 u0 += a * h0[i];
-                u1 += a * h1[i];
+                if constexpr (CT == 4) u1 += a * h1[i];
             }
             t0[j] = u0 >= 0.f ? u0 : u0 * s0;
             t1[j] = u1 >= 0.f ? u1 : u1 * s1;
         }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { h0[j] = t0[j]; h1[j] = t1[j]; }
+        for (int j = 0; j < 32; ++j) { h0[j] = t0[j]; if constexpr (CT == 4) h1[j] = t1[j]; }
     }
     // P5 (matrix cores): per 32-column tile of c' and 32-row tile of c
     //   Zt[c'][c]  = W8[c'][:] . h3[c][:] + b8[c']            16 x v_mfma_f32_32x32x2_f32  (A = W8 tile, B = h3^T)
     //   Mt         = sigmoid(Zt)                              = M_channel[c][c'] transposed, in accumulator layout
     //   fcT[p][c] += X[p][c'] * Mt[c'][c]                     2 x 16 MFMAs; the accumulator tile Mt IS the B operand:
     //       k-step r feeds register r (lanes 0-31 hold row (r&3)+8(r>>2), lanes 32-63 that row + 4), A = X^T from LDS
-    // Wave w owns rows c in [128w, 128w+128) = 4 column tiles of the MFMA output.
+    // Wave w owns rows c in [row_base, row_base + 32 CT) = CT column tiles of the MFMA output.
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     const int mj = lane & 31, mh = lane >> 5;
-    float HB[4][16];
+    float HB[CT][16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        // h3 of row 128w + 32ct + mj lives in lane (32*(ct&1) + mj), array h0 (ct < 2) or h1 (ct >= 2)
+        // h3 of row row_base + 32ct + mj lives in lane (32*(ct&1) + mj), array h0 (ct < 2) or h1 (ct >= 2)
         const float e0 = __shfl(h0[2 * ks], mj, 64), o0 = __shfl(h0[2 * ks + 1], mj, 64);
-        const float e1 = __shfl(h0[2 * ks], 32 + mj, 64), o1 = __shfl(h0[2 * ks + 1], 32 + mj, 64);
-        const float e2 = __shfl(h1[2 * ks], mj, 64), o2 = __shfl(h1[2 * ks + 1], mj, 64);
-        const float e3 = __shfl(h1[2 * ks], 32 + mj, 64), o3 = __shfl(h1[2 * ks + 1], 32 + mj, 64);
         HB[0][ks] = mh ? o0 : e0;
-        HB[1][ks] = mh ? o1 : e1;
-        HB[2][ks] = mh ? o2 : e2;
-        HB[3][ks] = mh ? o3 : e3;
+        if constexpr (CT >= 2) {
+            const float e1 = __shfl(h0[2 * ks], 32 + mj, 64), o1 = __shfl(h0[2 * ks + 1], 32 + mj, 64);
+            HB[1][ks] = mh ? o1 : e1;
+        }
+        if constexpr (CT == 4) {
+            const float e2 = __shfl(h1[2 * ks], mj, 64), o2 = __shfl(h1[2 * ks + 1], mj, 64);
+            const float e3 = __shfl(h1[2 * ks], 32 + mj, 64), o3 = __shfl(h1[2 * ks + 1], 32 + mj, 64);
+            HB[2][ks] = mh ? o2 : e2;
+            HB[3][ks] = mh ? o3 : e3;
+        }
     }
-    f32x16 fc[4][2];
+    f32x16 fc[CT][2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
             xa[1][r] = XT[cprow * XT_LD + p_hi];
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = bz[r];
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
             if (dbg_M && n == 0) {      // parity tests only: M_channel[c][c'] of image 0, straight from the accumulator tile
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    dbg_M[(128 * wave + 32 * ct + mj) * 512 + cpt * 32 + (r & 3) + 8 * (r >> 2) + 4 * mh] = z[r];
+                    dbg_M[(row_base + 32 * ct + mj) * 512 + cpt * 32 + (r & 3) + 8 * (r >> 2) + 4 * mh] = z[r];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -247,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
     // P6: feat_channel at channels [512,1024), its W-flip (torch.flip(.,[3])) at [0,512)
     float* Fn = bufF + (size_t)n * 49 * pitchF;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int c = 128 * wave + 32 * ct + mj;
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = row_base + 32 * ct + mj;
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -264,17 +274,34 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
 }
 
 // w.w1b is passed TRANSPOSED ([512][32]) by the engine
+// row_blocks = 1, 2 or 4 blocks per image (0: chosen here from N and the CU count: the fewest rounds of one block per CU, weighted
+// with the measured time of a block of each shape)
 hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF, int N,
-                               hipStream_t stream, float* dbg_ss, float* dbg_M) {
+                               hipStream_t stream, float* dbg_ss, float* dbg_M, int num_cus, int row_blocks) {
     static bool attr_done = false;
     const size_t lds = (size_t)(512 * XT_LD + 512 + 49 * 32) * 4;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_channel_path, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return e;
+        const void* fns[3] = {(const void*)k_channel_path<4>, (const void*)k_channel_path<2>, (const void*)k_channel_path<1>};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_channel_path, dim3(N), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
+    if (row_blocks == 0) {
+        // one block per CU (113 KB of LDS): rounds x block time; block times measured on MI355X (us): whole image / half / quarter
+        const double t_block[3] = {245.0, 135.0, 80.0};
+        double best = 1e30;
+        for (int k = 0; k < 3; ++k) {
+            const int rb = 1 << k;
+            const double t = (double)(((long long)N * rb + num_cus - 1) / num_cus) * t_block[k];
+            if (t < best - 1e-9) { best = t; row_blocks = rb; }
+        }
+    }
+    if (row_blocks == 4) hipLaunchKernelGGL(k_channel_path<1>, dim3(N, 4), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
+    else if (row_blocks == 2) hipLaunchKernelGGL(k_channel_path<2>, dim3(N, 2), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
+    else if (row_blocks == 1) hipLaunchKernelGGL(k_channel_path<4>, dim3(N, 1), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

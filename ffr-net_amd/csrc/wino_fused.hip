@@ -654,7 +654,8 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     if (FFR_TRACE_ON(a.trace) && lane == 0) {
         unsigned long long* tr = a.trace + ((size_t)blockIdx.x * 4 + wave) * 10;
         tr[0] = st0; tr[1] = st1; tr[2] = st2; tr[3] = __builtin_amdgcn_s_memtime();
-        tr[6] = se[0]; tr[7] = se[1]; tr[8] = se[2]; tr[9] = se[3];
+        tr[6] = se[0]; tr[7] = se[1];
+        tr[8] = NT == 2 ? se[2] : se[1]; tr[9] = NT == 2 ? se[3] : se[1];     // one pass only with 32-channel blocks
         if (PHASED) {       // per phase: transform, barrier wait (reported in the first two epilogue columns)
             tr[6] = st2 + se[0] / (nkc >> 2); tr[7] = tr[6] + (se[1] - se[0]) / (nkc >> 2); tr[8] = tr[7]; tr[9] = tr[7];
         }

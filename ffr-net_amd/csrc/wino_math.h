@@ -1,4 +1,4 @@
-// Vector types and the F(4x4,3x3) transform helpers shared by the fused Winograd kernels (wino_fused.hip, wino_fused_q.hip).
+// Vector types and the F(4x4,3x3) transform helpers shared by the fused Winograd kernels (wino_fused.hip, wino_mixed.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -123,6 +123,16 @@ __device__ __forceinline__ void combine_mixed_tiles(const WinoInMixedArgs& a, co
     const int t = (n_first + il) * 4 + q;                   // tile index within the type: 4 tiles per image
     float* vout = a.V[TAU] + (((size_t)(t >> 5) * a.nkc + kc) * XP) * 256 + (hf * 32 + (t & 31)) * 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x == gridDim.x - 1) {
+        // the rows of the last 32-tile group behind this block's two images: zero, as k_wino_in_mixed leaves them (V rows >= T
+        // are defined for every producer; the GEMM computes them and drops the results)
+        const int t_end = (int)((a.T[TAU] + 31) / 32) * 32;
+        for (int tz = (n_first + 2) * 4 + tile; tz < t_end; tz += 8) {
+            float* vz = a.V[TAU] + (((size_t)(tz >> 5) * a.nkc + kc) * XP) * 256 + (hf * 32 + (tz & 31)) * 4;
+#pragma unroll
+            for (int e = 0; e < XP; ++e) *reinterpret_cast<f32x4*>(vz + e * 256) = zero4;
+        }
+    }
     if (il >= n_imgs) {
 #pragma unroll
         for (int e = 0; e < XP; ++e) *reinterpret_cast<f32x4*>(vout + e * 256) = zero4;
@@ -190,6 +200,38 @@ __global__ __launch_bounds__(256) void k_combine_in_mixed(const float* __restric
         case 1: combine_mixed_tiles<4, 3>(a, s_x, n_first, n_imgs); break;
         case 2: combine_mixed_tiles<3, 4>(a, s_x, n_first, n_imgs); break;
         default: combine_mixed_tiles<3, 3>(a, s_x, n_first, n_imgs); break;
+    }
+}
+
+// ---- weights of the tile types (4,3), (3,4), (3,3): U = G_r g G_c^T from the packed direct weights, on the device ----------
+// (round 5: these three sets -- 24-48 MB per layer, 0.7 GB per handle -- were packed by the host at load time whether or not a
+// batch that uses them ever arrived; now the engine derives them from W[cout_pad][9][cin_pad] (BatchNorm already folded) the
+// first time a launch is eligible: engine.cpp, prepare_mixed_weights.)  One thread per (output channel, input channel); fp64
+// arithmetic, rounded once.  Output in fragment order [cout_pad/64][K chunk][XP][128 pieces][4]; padded xi stay zero (memset).
+__global__ __launch_bounds__(256) void k_wino_weights_mixed(const float* __restrict__ w, float* __restrict__ um, int cout_pad, int cin_pad,
+                                                           int mr, int mc, int xp) {
+    const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const double G3[5][3] = {{0.5, 0, 0}, {-0.5, -0.5, -0.5}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 6, 1.0 / 3, 2.0 / 3}, {0, 0, 1}};
+    const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
+    if (ci >= cin_pad) return;
+    double g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = (double)w[((size_t)co * 9 + t) * cin_pad + ci];
+    const int ar = mr + 2, ac = mc + 2, nkc = cin_pad / 8;
+    const int nb = co >> 6, nl = co & 63;
+    const int kc = ci >> 3, hf = (ci & 7) >> 2, e4 = ci & 3;
+    const int piece = (nl >> 5) * 64 + hf * 32 + (nl & 31);
+    float* dst = um + (((size_t)nb * nkc + kc) * xp * 128 + piece) * 4 + e4;
+    for (int i = 0; i < ar; ++i) {
+        const double* gr = mr == 4 ? G4[i] : G3[i];
+        double tmp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tmp[c] = gr[0] * g[0 * 3 + c] + gr[1] * g[1 * 3 + c] + gr[2] * g[2 * 3 + c];
+        for (int j = 0; j < ac; ++j) {
+            const double* gc = mc == 4 ? G4[j] : G3[j];
+            dst[(size_t)(i * ac + j) * 512] = (float)(tmp[0] * gc[0] + tmp[1] * gc[1] + tmp[2] * gc[2]);
+        }
     }
 }
 
@@ -266,6 +308,8 @@ __device__ __forceinline__ void fused_mixed_body(const WinoMixedArgs& a, int tau
     const int tid = threadIdx.x;
     const int nkc = a.nkc;
     const int n0 = nb * 64;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, sr0 = 0;      // trace build (option wf_trace): shader-clock stamps of the phases
+    if (FFR_TRACE_ON(a.trace)) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
     float* const s_bias = smem + WM_EPI_FLOATS;                       // [9][64] border-class biases of this channel group
     int* const s_tile = reinterpret_cast<int*>(s_bias + 9 * 64);     // [32][8]: origin pixel, valid, top/bottom row, left/right col, tile-sum slot
     for (int i = tid; i < (a.border_bias ? 9 : 1) * 64; i += 256) s_bias[i] = a.bias[(size_t)(i >> 6) * a.cout_pad + n0 + (i & 63)];
@@ -316,6 +360,7 @@ __device__ __forceinline__ void fused_mixed_body(const WinoMixedArgs& a, int tau
         FFR_PIN;
     }
     FFR_PIN;
+    if (FFR_TRACE_ON(a.trace)) st1 = __builtin_amdgcn_s_memtime();
     auto chunk = [&]<bool LAST>() {
 #pragma unroll
         for (int j = 0; j < S; ++j) {
@@ -343,6 +388,7 @@ __device__ __forceinline__ void fused_mixed_body(const WinoMixedArgs& a, int tau
         up += XP * 2048u;
     }
     chunk.template operator()<true>();
+    if (FFR_TRACE_ON(a.trace)) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue: two passes of 32 channels through E[xi][tile][32] in LDS (as k_wino_fused), transforms per tile type ----
     if (S == 9) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -419,6 +465,17 @@ __device__ __forceinline__ void fused_mixed_body(const WinoMixedArgs& a, int tau
             if (a.tile_sums) *reinterpret_cast<f32x4*>(a.tile_sums + (size_t)s_tile[tl * 8 + 4] * a.cout_pad + cg) = psum;
         }
         __syncthreads();
+        if (FFR_TRACE_ON(a.trace) && nt == 0) st3 = __builtin_amdgcn_s_memtime();
+    }
+    if (FFR_TRACE_ON(a.trace) && threadIdx.x == 0) {
+        unsigned long long* tr = a.trace + (size_t)blockIdx.x * 12;
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        tr[0] = st0; tr[1] = st1; tr[2] = st2; tr[3] = st3; tr[4] = __builtin_amdgcn_s_memtime();
+        tr[5] = sr0; tr[6] = __builtin_amdgcn_s_memrealtime();
+        tr[7] = ((unsigned long long)(xcc & 0xf) << 8) | ((hwid >> 8) & 0xff);     // XCD | (SE, SH, CU): one key per CU
+        tr[8] = (unsigned long long)tau; tr[9] = 1;
     }
 }
 #undef FFR_PIN
@@ -465,6 +522,29 @@ hipError_t launch_wino_fused_mixed(WinoMixedArgs a, hipStream_t stream) {
     }
     a.tpi_total = tpi;
     hipLaunchKernelGGL(k_wino_fused_mixed, dim3(tot), dim3(256), WM_LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+// grid size of launch_wino_fused_mixed (tile groups rounded up to 8 per type for the XCD-aware map)
+int wino_mixed_blocks_launched(int N, int H, int W, int cout_pad) {
+    WinoMixedGeom g;
+    if (!wino_mixed_geom(H, W, &g)) return 0;
+    long long T[4]; int groups[4];
+    wino_mixed_counts(g, N, T, groups);
+    int tot = 0;
+    for (int tau = 0; tau < 4; ++tau) tot += (groups[tau] + 7) / 8 * 8 * (cout_pad / 64);
+    return tot;
+}
+
+size_t wino_mixed_u_floats(int tau, int cout_pad, int cin_pad) { return (size_t)(cout_pad / 64) * (cin_pad / 8) * wino_mixed_xp(tau) * 512; }
+
+// um (wino_mixed_u_floats(tau, ..) floats, device) <- the weights of tile type tau in [1, 3] from the packed direct weights w
+hipError_t launch_wino_weights_mixed(const float* w, float* um, int cout_pad, int cin_pad, int tau, hipStream_t stream) {
+    if (tau < 1 || tau > 3 || cout_pad % 64 || cin_pad % 32) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(um, 0, wino_mixed_u_floats(tau, cout_pad, cin_pad) * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wino_weights_mixed, dim3((cin_pad + 255) / 256, cout_pad), dim3(256), 0, stream, w, um, cout_pad, cin_pad,
+                       MIXED_MR[tau], MIXED_MC[tau], wino_mixed_xp(tau));
     return hipGetLastError();
 }
 

@@ -25,6 +25,12 @@ class TensorDesc(C.Structure):
                 ('shape', C.c_int64 * 4)]
 
 
+class MemStats(C.Structure):
+    _fields_ = [('encoder_weight_bytes', C.c_size_t), ('recnet_weight_bytes', C.c_size_t), ('mixed_tile_weight_bytes', C.c_size_t),
+                ('workspace_bytes', C.c_size_t), ('encoder_load_seconds', C.c_double), ('recnet_load_seconds', C.c_double),
+                ('mixed_tile_pack_seconds', C.c_double)]
+
+
 class KClassStat(C.Structure):
     _fields_ = [('launches', C.c_int64), ('ms', C.c_double), ('flops', C.c_double),
                 ('bytes', C.c_double), ('flops_executed', C.c_double), ('flops_useful', C.c_double)]
@@ -76,6 +82,7 @@ SYMBOLS = [
     ('ffr_workspace_bytes', C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_reserve', C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     ('ffr_generation', C.c_ulonglong, [_P]),
+    ('ffr_memory_stats', C.c_int, [_P, _P]),
     ('ffr_set_option', C.c_int, [_P, C.c_char_p, C.c_longlong]),
     ('ffr_get_option', C.c_int, [_P, C.c_char_p, C.POINTER(C.c_longlong)]),
     ('ffr_probe_mfma_peak', C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
@@ -354,6 +361,12 @@ class Engine(object):
     def generation(self):
         """Changes whenever the handle released device memory a captured hipGraph may point into."""
         return int(self.lib.ffr_generation(self._h))
+
+    def memory_stats(self):
+        """Device bytes and packing seconds of the handle (include/ffrnet.h: ffr_mem_stats)."""
+        st = MemStats()
+        self._ck(self.lib.ffr_memory_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in MemStats._fields_}
 
     def probe_mfma_peak(self, iters=20000):
         """(TFLOP/s, shader clock in GHz) of a register-resident fp32-MFMA loop on this device."""

@@ -178,11 +178,12 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
  *   "wf_mixed" (1)        1: 14x14 maps (stage 3) are tiled exactly, 4+4+3+3 per dimension, with four tile types F(4x4) / F(4x3) /
  *                         F(3x4) / F(3x3) in one launch (k_wino_fused_mixed) whenever every CU gets two blocks or more; 0: padded
- *                         F(4x4) tiles only.  Set BEFORE ffr_load_encoder (the three extra weight sets are packed at load time)
- *   "wf_q" (0)            1: launches that transform their own input run k_wino_fused_q (a wave owns all 36 xi of a
- *                         16-channel slice, v_mfma_f32_16x16x4_f32, output transform in registers): the round-4
- *                         experiment, as fast as k_wino_fused<1, 2> and not faster
- *   "igemm_tile64" (0)    1..4: tile shape forced for the large direct convolutions with 64 output channels
+ *                         F(4x4) tiles only.  May be changed at any time: the three extra weight sets are derived on the device the
+ *                         first time a launch is eligible (ffr_memory_stats reports their bytes and seconds)
+ *   "igemm_tile64" (0)    1..4: tile shape forced for the large direct convolutions with 64 output channels (ignored where the
+ *                         tile's width does not divide the padded channel count)
+ *   "channel_rows" (0)    k_channel_path (RecNet's channel branch): 1 / 2 / 4 blocks per image (128 CT rows of M_channel each);
+ *                         0 = chosen from the batch and the CU count (fewer images than CUs -> more blocks per image)
  *   "combine_v" (1)       1: a bottleneck's combine (res * scale + shortcut) also writes the Winograd transform V of its
  *                         output when the next unit's conv1 runs k_wino_fused from V (stage 3 / 4): k_combine_in_c
  *                         replaces k_combine + k_wino_in_c
@@ -196,6 +197,15 @@ int ffr_get_option(const ffr_handle* h, const char* name, long long* value);
  * arena, stream-K tickets, packed weights, training buffers) has been released and re-allocated.  A graph captured
  * around ffr_embed must be re-captured when this value differs from the one read at capture time.               */
 unsigned long long ffr_generation(const ffr_handle* h);
+/* Device memory and packing time of the handle (round 5; the reference's counterpart is `net.load_state_dict(...)` +
+ * `.to(device)`, models/trainer.py:98-113, which has no packing step).  mixed_tile_* are the three extra Winograd weight
+ * sets of the exact 14x14 tiling: derived on the device the first time a batch large enough to use them arrives
+ * (ffr_reserve / the first forward of >= 256 images), 0 before.                                                     */
+typedef struct ffr_mem_stats {
+    size_t encoder_weight_bytes, recnet_weight_bytes, mixed_tile_weight_bytes, workspace_bytes;
+    double encoder_load_seconds, recnet_load_seconds, mixed_tile_pack_seconds;
+} ffr_mem_stats;
+int ffr_memory_stats(const ffr_handle* h, ffr_mem_stats* out);
 /* fp32-MFMA rate this device delivers on a register-resident v_mfma_f32_32x32x2_f32 loop (iters x 16 MFMAs per
  * wave, 8 waves per CU) and the shader clock it holds meanwhile: the measured denominator of a roofline fraction. */
 int ffr_probe_mfma_peak(ffr_handle* h, int iters, double* tflops, double* clock_ghz, void* stream);

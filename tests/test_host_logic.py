@@ -95,6 +95,25 @@ def test_c_abi_exports_every_declared_symbol():
         assert rc != 0 and not h.value          # no device -> error code, never a CPU path
 
 
+def test_integration_lists_the_sources():
+    """INTEGRATION.md section 5 names the translation units of the library; held to SOURCES of
+    __graft_entry__.py (the experiment kernel k_wino_fused_q left the product in round 5 and must not come back unnoticed),
+    and the built library exports no symbol of it."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r'csrc/\{([^}]*)\}', text)
+    assert m, 'INTEGRATION.md section 5 lost its source list'
+    assert sorted(m.group(1).split(',')) == sorted(g.SOURCES)
+    assert all(os.path.exists(os.path.join(g.CSRC, f)) for f in g.SOURCES)
+    assert 'wino_fused_q.hip' not in g.SOURCES
+    out = subprocess.run(['nm', '-D', native.lib_path()], capture_output=True, text=True)
+    if out.returncode == 0:
+        assert 'wino_fused_q' not in out.stdout
+    raw = open(native.lib_path(), 'rb').read()
+    assert b'k_wino_fused_q' not in raw           # no such kernel in the embedded code object either
+
+
 def test_weight_cache_sees_submodule_surgery():
     """replacing a Parameter / buffer on a SUB-module must invalidate the packed native copy.  The
     signature the shells compare on every forward is (identity, version) of each tensor in the tree."""

@@ -31,9 +31,7 @@ python3 bench.py --pairs-per-step 512 --no-cpu-baseline --no-secondary > "$O/${R
 FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --pairs-per-step 512 --no-roofline --no-cpu-baseline 2>> "$O/bench.err" | grep '^{' > "$O/${RD}_bench_selflaunch_2ranks_gloo_one_device.json" || true
 python3 bench.py --workload train > "$O/${RD}_train_step.json" 2>> "$O/bench.err" || true
 python3 tools/wf_trace.py 2>&1 | grep "wf trace" > "$O/${RD}_wino_fused_phase_trace.txt" || true
-FFR_OPT_WF_Q=1 python3 tools/wf_trace.py 2>&1 | grep "wf trace" | grep -A1 "q form" | grep -v "^--" > "$O/${RD}_exp_wf_q_form_phase_trace.txt" || true
 python3 tools/stride2_experiments.py 256 2>/dev/null | grep -v "amdgpu.ids" > "$O/${RD}_exp_stride2_polyphase_lower_bound.txt" || true
-for q in 1 0; do python3 bench.py --no-cpu-baseline --no-secondary --opt wf_q=$q > "$O/${RD}_exp_bench_wf_q$q.json" 2>> "$O/bench.err" || true; done
 for m in 1 0; do python3 bench.py --no-cpu-baseline --no-secondary --opt wf_mixed=$m > "$O/${RD}_exp_bench_wf_mixed$m.json" 2>> "$O/bench.err" || true; done
 for t in 0 4; do python3 bench.py --no-cpu-baseline --no-secondary --opt igemm_tile64=$t > "$O/${RD}_exp_bench_igemm_tile64_$t.json" 2>> "$O/bench.err" || true; done
 TRACE=igemm_trace python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > "$O/${RD}_igemm_trace.txt" || true

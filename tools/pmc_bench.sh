@@ -28,7 +28,13 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob('$OUT/*/*/*counter_collection.csv'):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Dispatch_Id']))
     stems = sorted({int(r['Dispatch_Id']) for r in rows if 'k_stem' in r['Kernel_Name']})
-    first = stems[1] if len(stems) > STEPS else stems[0]          # dispatch id of the first batch-256 forward
+    # dispatch id of the first counted forward: embed = the batch-8 parity forward + STEPS forwards (one k_stem each), train =
+    # STEPS iterations (one k_stem each: clean + occluded images in one encoder pass).  Anything else means bench.py changed
+    # what it launches and the per-step figures below would be skewed: fail instead of guessing.
+    want = STEPS + 1 if WL == 'embed' else STEPS
+    if len(stems) != want:
+        raise SystemExit('pmc_bench: %d k_stem launches in %s, expected %d for workload %s' % (len(stems), f, want, WL))
+    first = stems[1] if WL == 'embed' else stems[0]
     for r in rows:
         if int(r['Dispatch_Id']) < first:
             continue

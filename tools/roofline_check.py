@@ -44,7 +44,7 @@ def main():
     n = b['config']['batch_per_gpu']
     calls = ns = 0
     for row in csv.DictReader(open(stats)):
-        if 'k_wino_fused' in row['Name']:          # k_wino_fused<.,.>, k_wino_fused_mixed (and k_wino_fused_q when selected)
+        if 'k_wino_fused' in row['Name']:          # k_wino_fused<.,.>, k_wino_fused_mixed
             calls += int(row['Calls'])
             ns += int(row['TotalDurationNs'])
     avg_us = ns / calls / 1e3
