@@ -496,6 +496,7 @@ def train_workload(args, world, rank, local, dist):
 
 
 def main():
+    t_start = time.perf_counter()
     args = parse_args()
     # Cross-process GPU memory sharing (RCCL's intra-node transport, torch's CUDA-tensor IPC) needs dmabuf IPC handles on
     # this image's host driver: with the legacy mode RCCL fails in hipIpcGetMemHandle ("invalid argument").  The image
@@ -597,6 +598,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    startup_s = time.perf_counter() - t_start      # process start -> first step: imports, rendezvous, weight synthesis, packing, parity gate
     for _ in range(args.warmup):
         step()
     fence()
@@ -617,15 +619,19 @@ def main():
         # scaling loss can be attributed: a slow rank, the collective, or the launch path
         mine = torch.tensor([dt_local / args.steps * 1e3,
                              percentiles([a.elapsed_time(b) for a, b in evs])['median'],
-                             percentiles([a.elapsed_time(b) for a, b in coll_ev])['median']], device=dev, dtype=torch.float64)
-        flat = torch.empty(world * 3, device=dev, dtype=torch.float64)
+                             percentiles([a.elapsed_time(b) for a, b in coll_ev])['median'], startup_s], device=dev, dtype=torch.float64)
+        flat = torch.empty(world * 4, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(flat, mine)
-        allr = flat.view(world, 3)
+        allr = flat.view(world, 4)
         dt = allr[:, 0].max().item() * args.steps / 1e3                      # MAX over ranks
         per_rank = {'wall_ms_per_step': [round(v, 3) for v in allr[:, 0].tolist()],
                     'step_ms_hipevents_median': [round(v, 3) for v in allr[:, 1].tolist()],
                     'all_gather_ms_hipevents_median': [round(v, 4) for v in allr[:, 2].tolist()],
                     'all_gather_bytes_per_rank': 2 * B * 512 * 4,
+                    'startup_s': [round(v, 2) for v in allr[:, 3].tolist()],
+                    'startup_note': 'process start -> first step (imports, rendezvous, weight synthesis with host_cores // world torch '
+                                    'threads, single-threaded packing, parity gate); the rendezvous / collective timeout is '
+                                    'FFR_BENCH_DIST_TIMEOUT (default 600 s)',
                     'note': 'the all-gather event pair also waits for the slowest rank to arrive'}
         # the exchange put every rank's rows where the scoring reads them: this rank's slice is its own output
         assert torch.equal(gathered[rank], pack), 'all-gather: rank %d does not find its own embeddings' % rank
@@ -742,7 +748,7 @@ def main():
     # BN folding, Winograd weight transforms, fragment orders; torch.set_num_threads above does not matter: the packer is one
     # thread) and of the first ffr_reserve, and what the handle holds afterwards
     ms_ = eng.memory_stats()
-    load = {'load_s': round(t_load, 3), 'reserve_s': round(t_res, 3),
+    load = {'startup_s': round(startup_s, 2), 'load_s': round(t_load, 3), 'reserve_s': round(t_res, 3),
             'encoder_load_s': round(ms_['encoder_load_seconds'], 3), 'recnet_load_s': round(ms_['recnet_load_seconds'], 3),
             'mixed_tile_pack_s': round(ms_['mixed_tile_pack_seconds'], 4),
             'weight_gb': round((ms_['encoder_weight_bytes'] + ms_['recnet_weight_bytes']) / 1e9, 3),

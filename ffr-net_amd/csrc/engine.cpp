@@ -952,6 +952,29 @@ int run_recnet(ffr_handle* h, const Work& w, int N, float* f_new, const RecDebug
         // ss_channel Gram + Conv4Channel (6 linears) + M_channel @ X, algorithmic (unfused) count
         const double fl = 2.0 * N * (512.0 * 512 * 49 + 512.0 * (561 * 32 + 5 * 32 * 512) + 512.0 * 512 * 49);
         Scope s(h, st, FFR_KC_CHANNEL, fl, 4.0 * N * (49 * 512 * 3));
+#ifdef FFR_TRACE
+        if (h->opt.wf_trace) {
+            unsigned long long* dbuf = nullptr;
+            HIPCK(h, hipMalloc((void**)&dbuf, (size_t)N * 4 * 8 * sizeof(unsigned long long)));
+            HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)N * 4 * 8 * sizeof(unsigned long long), st));
+            int rb = 0;
+            HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st, nullptr, nullptr, h->num_cus, h->opt.channel_rows, dbuf, &rb));
+            HIPCK(h, hipStreamSynchronize(st));
+            std::vector<unsigned long long> tr((size_t)N * 4 * 8);
+            HIPCK(h, hipMemcpy(tr.data(), dbuf, tr.size() * 8, hipMemcpyDeviceToHost));
+            HIPCK(h, hipFree(dbuf));
+            double ph[6] = {0, 0, 0, 0, 0, 0}; int cnt = 0;
+            for (int b = 0; b < N * rb; ++b) {
+                const unsigned long long* q = &tr[(size_t)b * 8];
+                if (!q[6]) continue;
+                for (int i = 0; i < 6; ++i) ph[i] += (double)(q[i + 1] - q[i]);
+                ++cnt;
+            }
+            fprintf(stderr, "[wf trace] k_channel_path, %d images x %d row blocks: per block (wave 0) transpose+norms %.0f | G on MFMA %.0f | first linear %.0f | "
+                            "two 32x32 affines %.0f | sigmoid(W8 h) @ X on MFMA %.0f | stores %.0f cyc\n", N, rb, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt,
+                    ph[4] / cnt, ph[5] / cnt);
+        } else
+#endif
         HIPCK(h, launch_channel_path(w.X, h->cw, w.bufF, 1024, N, st, dbg ? dbg->ss_channel0 : nullptr, dbg ? dbg->M_channel0 : nullptr, h->num_cus,
                                      h->opt.channel_rows));
     }

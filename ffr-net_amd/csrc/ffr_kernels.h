@@ -205,7 +205,8 @@ struct ChannelPathWeights {   // device pointers, see engine.cpp pack_recnet()
 // bufF[n,p,512+c] and W-flipped to bufF[n,flip(p),c]  (bufF pitch 1024)
 // dbg_ss / dbg_M (parity tests, optional): ss_channel and M_channel [512][512] of image 0, which the path never stores
 hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF, int N, hipStream_t stream,
-                               float* dbg_ss, float* dbg_M, int num_cus, int row_blocks /* 0 auto | 1 | 2 | 4 blocks per image */);
+                               float* dbg_ss, float* dbg_M, int num_cus, int row_blocks /* 0 auto | 1 | 2 | 4 blocks per image */,
+                               unsigned long long* trace = nullptr /* -DFFR_TRACE: 8 words per block */, int* row_blocks_used = nullptr);
 // feat_space: out[n,j,c] = sum_i ms[n,j,i] * X[n,i,c]   (ms pitch = ms_pitch, out pitch/coff)
 hipError_t launch_space_apply(const float* X, const float* ms, int ms_pitch, float* out, int out_pitch,
                               int out_coff, int N, hipStream_t stream);

@@ -95,11 +95,12 @@ hipError_t launch_selfsim_space(const float* X, float* bufS, int pitchS, float* 
 template <int CT>
 __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict__ X, const ChannelPathWeights w,
                                                      const float* __restrict__ w1bT, float* __restrict__ bufF,
-                                                     int pitchF, float* __restrict__ dbg_ss, float* __restrict__ dbg_M) {
+                                                     int pitchF, float* __restrict__ dbg_ss, float* __restrict__ dbg_M,
+                                                     unsigned long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* XT = sm;                       // [512][52]  X transposed: channel-major
     float* inv = XT + 512 * XT_LD;        // [512] 1/max(|X_c|,eps)
-    float* G = inv + 512;                 // [49][32]
+    float* G = inv + 512;                 // [49][32], followed by the waves' partial tiles [4][64][32] (P2)
     const int n = blockIdx.x, tid = threadIdx.x;
     const float* Xn = X + (size_t)n * 49 * 512;
     const int c0 = tid, c1 = tid + 256;                       // columns this thread transposes in P1
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
     const int row_base = blockIdx.y * (128 * CT) + 32 * CT * wave;      // first row of this wave
     // rows whose MLP this thread evaluates (P3, P4): CT = 4: two rows per lane; CT = 2: one; CT = 1: lanes 32-63 repeat lanes 0-31
     const int r0 = row_base + (CT == 1 ? (lane & 31) : lane), r1 = CT == 4 ? r0 + 64 : r0;
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};       // trace build (option wf_trace): phase stamps of wave 0
+    if (FFR_TRACE_ON(trace)) ts[0] = __builtin_amdgcn_s_memtime();
 
     {   // P1: transpose into LDS + channel norms
         float s0 = 0.f, s1 = 0.f;
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
         inv[c1] = 1.0f / fmaxf(sqrtf(s1), 1e-12f);
     }
     __syncthreads();
+    if (FFR_TRACE_ON(trace)) ts[1] = __builtin_amdgcn_s_memtime();
     if (dbg_ss && n == 0 && blockIdx.y == 0) {     // parity tests only: ss_channel of image 0 from the normalised vectors the path uses
         for (int o = tid; o < 512 * 512; o += 256) {
             const int c = o >> 9, cp = o & 511;
@@ -130,14 +134,58 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
             dbg_ss[o] = s * inv[c] * inv[cp];
         }
     }
-    // P2: G[p][j] = sum_c Xhat[p][c] * W1b[j][c]   (w1bT = [512][32])
-    for (int o = tid; o < 49 * 32; o += 256) {
-        const int p = o >> 5, j = o & 31;
-        float s = 0.f;
-        for (int c = 0; c < 512; ++c) s += XT[c * XT_LD + p] * inv[c] * w1bT[c * 32 + j];
-        G[o] = s;
+    // P2 (matrix cores, round 5): G[p][j] = sum_c Xhat[p][c] * W1b[j][c]   (w1bT = [512][32]) as G^T = W1b * Xhat^T: M = 32 (j), N = 2 x 32
+    // positions (49 -> 64), K = 512 split over the four waves (128 channels = 64 k-steps of v_mfma_f32_32x32x2_f32 each), partial tiles
+    // through LDS, added in wave order.  (The scalar form -- 6 outputs per thread, 512 dependent-latency iterations of two LDS reads and
+    // one L2 load each -- took ~90 of the kernel's 245 us.)
+    {
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        const int pj = lane & 31, kh = lane >> 5;
+        const int p_hi2 = (32 + pj) < 51 ? (32 + pj) : 51;         // XT[..][49..51] are zeros
+        f32x16 g0, g1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+        float av[64];                       // every A value of the wave's K range requested up front: ONE memory latency, not 64 (45k -> cycles of the MFMAs)
+#pragma unroll
+        for (int ks = 0; ks < 64; ++ks) av[ks] = w1bT[(128 * wave + 2 * ks + kh) * 32 + pj];      // A[m = j][k = c]
+#pragma unroll
+        for (int ks = 0; ks < 64; ++ks) {
+            const int c = 128 * wave + 2 * ks + kh;
+            const float iv = inv[c];
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], XT[c * XT_LD + pj] * iv, g0, 0, 0, 0);        // B[k = c][n = p]
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], XT[c * XT_LD + p_hi2] * iv, g1, 0, 0, 0);
+        }
+        // accumulator register r of lane l = G^T[j = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][p = l & 31 (+ 32)]
+        float* Gp = G + 49 * 32 + wave * (64 * 32);                // [4 waves][64 positions][32]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            Gp[pj * 32 + j] = g0[r];
+            Gp[(32 + pj) * 32 + j] = g1[r];
+        }
     }
     __syncthreads();
+    float gsum[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int o = tid + 256 * k;
+        const float* Gp = G + 49 * 32;
+        gsum[k] = o < 49 * 32 ? ((Gp[o] + Gp[64 * 32 + o]) + Gp[2 * 64 * 32 + o]) + Gp[3 * 64 * 32 + o] : 0.f;
+    }
+    __syncthreads();                      // everybody has read the partial tiles: their LDS now takes the small weight matrices
+    // W1a^T [49][32], A2 [32][32], A3 [32][32] for P3 / P4: 16-byte broadcast reads from LDS instead of one scalar global load per value
+    float* const sW1 = G + 49 * 32;
+    float* const sA2 = sW1 + 49 * 32;
+    float* const sA3 = sA2 + 32 * 32;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int o = tid + 256 * k;
+        if (o < 49 * 32) { G[o] = gsum[k]; sW1[o] = w.w1a[(o & 31) * 49 + (o >> 5)]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sA2[tid + 256 * k] = w.A2[tid + 256 * k]; sA3[tid + 256 * k] = w.A3[tid + 256 * k]; }
+    __syncthreads();
+    if (FFR_TRACE_ON(trace)) ts[2] = __builtin_amdgcn_s_memtime();
     // P3: h[j] = b1[j] + sum_p X[p][c] * (W1a[j][p] + inv_c * G[p][j])
     float h0[32], h1[32];
     const float i0 = inv[r0], i1 = inv[r1];
@@ -146,12 +194,16 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
     for (int p = 0; p < 49; ++p) {
         const float x0 = XT[r0 * XT_LD + p], x1 = XT[r1 * XT_LD + p];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const float wa = w.w1a[j * 49 + p], g = G[p * 32 + j];
-            h0[j] += x0 * (wa + i0 * g);
-            if constexpr (CT == 4) h1[j] += x1 * (wa + i1 * g);
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(sW1 + p * 32 + 4 * q), g = *reinterpret_cast<const f32x4*>(G + p * 32 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h0[4 * q + e] += x0 * (wa[e] + i0 * g[e]);
+                if constexpr (CT == 4) h1[4 * q + e] += x1 * (wa[e] + i1 * g[e]);
+            }
         }
     }
+    if (FFR_TRACE_ON(trace)) ts[3] = __builtin_amdgcn_s_memtime();
     // P4: PReLU (slope per row c), two folded 32x32 affines with PReLU after each
     {
         const float s0 = w.a1[r0], s1 = w.a1[r1];
@@ -163,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
     }
 #pragma unroll 1
     for (int layer = 0; layer < 2; ++layer) {
-        const float* A = layer == 0 ? w.A2 : w.A3;
+        const float* A = layer == 0 ? sA2 : sA3;
         const float* d = layer == 0 ? w.d2 : w.d3;
         const float* sl = layer == 0 ? w.a4 : w.a7;
         const float s0 = sl[r0], s1 = sl[r1];
@@ -172,10 +224,13 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
         for (int j = 0; j < 32; ++j) {
             float u0 = d[j], u1 = d[j];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float a = A[j * 32 + i];
-                u0 += a * h0[i];
-                if constexpr (CT == 4) u1 += a * h1[i];
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(A + j * 32 + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u0 += a[e] * h0[4 * q + e];
+                    if constexpr (CT == 4) u1 += a[e] * h1[4 * q + e];
+                }
             }
             t0[j] = u0 >= 0.f ? u0 : u0 * s0;
             t1[j] = u1 >= 0.f ? u1 : u1 * s1;
@@ -183,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 32; ++j) { h0[j] = t0[j]; if constexpr (CT == 4) h1[j] = t1[j]; }
     }
+    if (FFR_TRACE_ON(trace)) ts[4] = __builtin_amdgcn_s_memtime();
     // P5 (matrix cores): per 32-column tile of c' and 32-row tile of c
     //   Zt[c'][c]  = W8[c'][:] . h3[c][:] + b8[c']            16 x v_mfma_f32_32x32x2_f32  (A = W8 tile, B = h3^T)
     //   Mt         = sigmoid(Zt)                              = M_channel[c][c'] transposed, in accumulator layout
@@ -254,6 +310,7 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
             }
         }
     }
+    if (FFR_TRACE_ON(trace)) ts[5] = __builtin_amdgcn_s_memtime();
     // P6: feat_channel at channels [512,1024), its W-flip (torch.flip(.,[3])) at [0,512)
     float* Fn = bufF + (size_t)n * 49 * pitchF;
 #pragma unroll
@@ -271,15 +328,23 @@ __global__ __launch_bounds__(256, 1) void k_channel_path(const float* __restrict
                 }
             }
     }
+    if (FFR_TRACE_ON(trace) && tid == 0) {
+        ts[6] = __builtin_amdgcn_s_memtime();
+        unsigned long long* tr = trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tr[i] = ts[i];
+        tr[7] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // w.w1b is passed TRANSPOSED ([512][32]) by the engine
 // row_blocks = 1, 2 or 4 blocks per image (0: chosen here from N and the CU count: the fewest rounds of one block per CU, weighted
 // with the measured time of a block of each shape)
 hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, float* bufF, int pitchF, int N,
-                               hipStream_t stream, float* dbg_ss, float* dbg_M, int num_cus, int row_blocks) {
+                               hipStream_t stream, float* dbg_ss, float* dbg_M, int num_cus, int row_blocks, unsigned long long* trace,
+                               int* row_blocks_used) {
     static bool attr_done = false;
-    const size_t lds = (size_t)(512 * XT_LD + 512 + 49 * 32) * 4;
+    const size_t lds = (size_t)(512 * XT_LD + 512 + 49 * 32 + 4 * 64 * 32) * 4;      // X^T, 1/norm, G, the four waves' partial G tiles
     if (!attr_done) {
         const void* fns[3] = {(const void*)k_channel_path<4>, (const void*)k_channel_path<2>, (const void*)k_channel_path<1>};
         for (const void* f : fns) {
@@ -290,7 +355,7 @@ hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, floa
     }
     if (row_blocks == 0) {
         // one block per CU (113 KB of LDS): rounds x block time; block times measured on MI355X (us): whole image / half / quarter
-        const double t_block[3] = {245.0, 135.0, 80.0};
+        const double t_block[3] = {200.0, 140.0, 110.0};
         double best = 1e30;
         for (int k = 0; k < 3; ++k) {
             const int rb = 1 << k;
@@ -298,10 +363,11 @@ hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, floa
             if (t < best - 1e-9) { best = t; row_blocks = rb; }
         }
     }
-    if (row_blocks == 4) hipLaunchKernelGGL(k_channel_path<1>, dim3(N, 4), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
-    else if (row_blocks == 2) hipLaunchKernelGGL(k_channel_path<2>, dim3(N, 2), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
-    else if (row_blocks == 1) hipLaunchKernelGGL(k_channel_path<4>, dim3(N, 1), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M);
+    if (row_blocks == 4) hipLaunchKernelGGL(k_channel_path<1>, dim3(N, 4), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M, trace);
+    else if (row_blocks == 2) hipLaunchKernelGGL(k_channel_path<2>, dim3(N, 2), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M, trace);
+    else if (row_blocks == 1) hipLaunchKernelGGL(k_channel_path<4>, dim3(N, 1), dim3(256), lds, stream, X, w, w.w1b, bufF, pitchF, dbg_ss, dbg_M, trace);
     else return hipErrorInvalidValue;
+    if (row_blocks_used) *row_blocks_used = row_blocks;
     return hipGetLastError();
 }
 
