@@ -355,7 +355,7 @@ hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, floa
     }
     if (row_blocks == 0) {
         // one block per CU (113 KB of LDS): rounds x block time; block times measured on MI355X (us): whole image / half / quarter
-        const double t_block[3] = {200.0, 140.0, 110.0};
+        const double t_block[3] = {181.0, 140.0, 101.0};     // profiles/r05_channel_path_phase_trace.txt
         double best = 1e30;
         for (int k = 0; k < 3; ++k) {
             const int rb = 1 << k;
