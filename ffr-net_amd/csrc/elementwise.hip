@@ -16,13 +16,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------
 // Stem: Conv3x3(3->64, pad 1, no bias) + BN + PReLU   (pretrain/model_ir_se50.py:118-120)
-// Block = 256 threads; 64 pixels per step: the 27-tap patches are staged in LDS ([pix][28], slot 27 = 0) by
-// 4 threads per pixel, then the [64 px x 28] x [28 x 64 ch] product runs on the matrix cores
-// (v_mfma_f32_32x32x2_f32, one 32x32 output tile per wave, 14 k-steps): the weights of a wave's 32
-// channels stay in 14 registers per lane, bias + PReLU on the accumulator, 128-byte NHWC stores.
+// Block = 256 threads; 64 pixels per step: the 27-tap patches are staged in LDS (tap-major [28][64 pixels], slot 27 = 0; wave w
+// fetches taps 7w..7w+6, lane = pixel: coalesced 256-byte reads of the NCHW planes), then the [64 px x 28] x [28 x 64 ch] product
+// runs on the matrix cores (v_mfma_f32_32x32x2_f32, one 32x32 output tile per wave, 14 k-steps): the weights of a wave's 32
+// channels stay in 14 registers per lane, bias + PReLU on the accumulator, which leaves through a wave-private LDS tile as 16
+// bytes per lane (NHWC, 8 lanes per 128-byte half line).
 // ---------------------------------------------------------------------------------------
 #define STEM_PIX 64
 #define STEM_STEPS 8
+#define STEM_TLD 36
 // U8 = true: the input is the decoded image itself, uint8 [N,H,W,3] RGB, and the reference's input
 // step is applied on the fly (data/dataset.py:70-79, data/dataloader.py:24-28): RGB->BGR channel
 // swap, optional horizontal flip (one flag per image), ToTensor (/255) and Normalize(0.5, 0.5),
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
                                              float* __restrict__ out, int N, int H, int W,
                                              const float* __restrict__ x2, int n_split) {
     __shared__ __attribute__((aligned(16))) float patch[STEM_PIX * 28];
+    __shared__ __attribute__((aligned(16))) float otile[4 * 32 * STEM_TLD];      // per wave: its output tile [32 pixels][32 channels (+4)]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int mt = wave >> 1, nt = wave & 1;          // this wave's 32-pixel x 32-channel output tile
@@ -48,20 +51,22 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
     }
     const float b = bias[ch], sl = slope[ch];
 
-    int f_ci[7], f_dr[7], f_ds[7];          // tap geometry of this thread's 7 fill slots
+    // fill (round 5): wave w fetches taps 7w .. 7w+6 (k = (ci*3 + r)*3 + s; k == 27 is the zero pad), LANE = pixel of the step: a
+    // wave-load reads 64 consecutive pixels of one input plane row (256 contiguous bytes; the 16-lane groups of round 4's mapping --
+    // 4 pixels x 4 taps -- touched four different rows / planes each and the fill, not the 822 MB of stores, set the kernel's time).
+    // The patch image in LDS is tap-major [28][64 pixels]: the fill's writes and the MFMA operand reads are both conflict-free.
+    // The values of step s + 1 are fetched into registers while step s multiplies.
+    int f_ci[7], f_dr[7], f_ds[7];          // tap geometry of this wave's 7 fill slots
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const int k = (tid & 3) * 7 + i;
+        const int k = wave * 7 + i;
         f_ci[i] = k / 9;                     // 3 = the padding slot k == 27
         f_dr[i] = (k - f_ci[i] * 9) / 3 - 1;
         f_ds[i] = k % 3 - 1;
     }
-    // fill: 4 threads per pixel, 7 taps each (k = (ci*3 + r)*3 + s, k == 27 is padding): ONE pixel decomposition
-    // per thread and step; the tap geometry of a thread never changes.  The values of step s + 1 are fetched
-    // into registers while step s multiplies.
     float nv[7];
     auto fetch = [&](int step) {
-        const long long p = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX + (tid >> 2);
+        const long long p = ((long long)blockIdx.x * STEM_STEPS + step) * STEM_PIX + lane;
         const bool pv = p < total;
         const int n = pv ? (int)((unsigned)p / (unsigned)HW) : 0;      // p < N * H * W < 2^31 (launch_stem): 32-bit divisions
         const int rem = pv ? (int)((unsigned)p - (unsigned)n * (unsigned)HW) : 0;
@@ -91,22 +96,38 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ x, const
         if (p0 >= total) break;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 7; ++i) patch[(tid >> 2) * 28 + (tid & 3) * 7 + i] = nv[i];
+        for (int i = 0; i < 7; ++i) patch[(wave * 7 + i) * STEM_PIX + lane] = nv[i];
         __syncthreads();
         if (step + 1 < STEM_STEPS) fetch(step + 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* pa = patch + (mt * 32 + (lane & 31)) * 28 + half;
+        const float* pa = patch + half * STEM_PIX + mt * 32 + (lane & 31);
 #pragma unroll
-        for (int ks = 0; ks < 14; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * ks], wr[ks], acc, 0, 0, 0);
-        // accumulator: channel = lane & 31 (+ 32 nt), pixel row = (r & 3) + 8 (r >> 2) + 4 half
+        for (int ks = 0; ks < 14; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[2 * ks * STEM_PIX], wr[ks], acc, 0, 0, 0);
+        // accumulator: channel = lane & 31 (+ 32 nt), pixel row = (r & 3) + 8 (r >> 2) + 4 half.  Stored straight from there a
+        // wave-store is 64 lanes x 4 bytes (two 128-byte half lines): the kernel then runs at the STORE-INSTRUCTION rate of the
+        // CU's memory path (~12 cycles per 16-lane group whatever the bytes per lane: 3.3 TB/s, round 4).  Round 5: the wave's
+        // 32 pixel x 32 channel tile goes through a wave-private LDS tile and leaves as 16 bytes per lane, 8 lanes per half line:
+        // a quarter of the store instructions for the same bytes.
+        float* const tw_ = otile + wave * (32 * STEM_TLD);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long long p = p0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = acc[r] + b;
             v = v >= 0.f ? v : v * sl;
-            if (p < total) out[p * 64 + ch] = v;
+            tw_[((r & 3) + 8 * (r >> 2) + 4 * half) * STEM_TLD + (lane & 31)] = v;
+        }
+        // same wave wrote and reads: no workgroup barrier, the LDS executes a wave's operations in order (the compiler is told not to
+        // move the reads over the writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px = (lane >> 3) + 8 * q;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tw_ + px * STEM_TLD + (lane & 7) * 4);
+            const long long p = p0 + mt * 32 + px;
+            if (p < total) *reinterpret_cast<f32x4*>(out + p * 64 + nt * 32 + (lane & 7) * 4) = v;
         }
     }
 }
