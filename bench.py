@@ -755,7 +755,7 @@ def main():
             'mixed_tile_weight_gb': round(ms_['mixed_tile_weight_bytes'] / 1e9, 3),
             'workspace_gb': round(ms_['workspace_bytes'] / 1e9, 3),
             'note': 'mixed_tile_*: the three extra Winograd weight sets of the exact 14x14 tiling, derived on the device at the first '
-                    'reserve / forward of a batch that uses them (>= 128 images), 0 for handles that only see smaller batches'}
+                    'reserve / forward of a batch that uses them (>= 256 images; >= 128 for the 256 -> 512 layer), 0 for handles that only see smaller batches'}
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary and not strong:

@@ -211,7 +211,7 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
 }
 
 // True when the convolution WOULD run on the exact 4+4+3+3 tiling (k_wino_fused_mixed) once the three extra weight sets exist:
-// 14x14 map, zero padding, scratch large enough, and every CU gets at least one block.
+// 14x14 map, zero padding, scratch large enough, and every CU gets at least two blocks.
 // wino_mode 4 forces it (tests, experiments; 7x7 maps = 4+3 too).
 bool wino_mixed_eligible(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
     if (!L.wuc || !L.w || L.R != 3 || L.S != 3 || L.stride != 1 || L.pad_mode != 0 || in_pitch != L.cin_pad) return false;
@@ -221,9 +221,10 @@ bool wino_mixed_eligible(const ffr_handle* h, const ConvW& L, int N, int H, int 
     if (wino_mode == 4) return true;
     if (wino_mode >= 0 || !h->opt.wino || !h->opt.wino_fused || !h->opt.wf_mixed) return false;
     // >= 2 blocks per CU: a long block pairs with a short one (16 instead of 18 slots per CU).  With ONE block per CU the (4,4) blocks
-    // set the time and the fused kernel gains nothing, but the launch still wins 10 % because V is 16 % smaller and its transform
-    // cheaper (round 5, tools/mixed7_experiment.py: 256 -> 256 at 128 images: 94.4 + 39.4 us padded vs 92.7 + 28.4 us exact)
-    return wino_mixed_blocks(N, H, W, L.cout_pad) >= h->num_cus;
+    // set the time: a single launch still wins 7 % there because V is 16 % smaller (round 5, tools/mixed7_experiment.py: 256 -> 256
+    // at 128 images: 95.1 + 31.8 us padded vs 92.9 + 24.9 us exact), but in the forward, where the transform rides in the combine
+    // kernel, it is a tie (14.68 k vs 14.70 k embeddings/s at 128 images) and would cost the 0.7 GB of extra weight sets
+    return wino_mixed_blocks(N, H, W, L.cout_pad) >= 2 * h->num_cus;
 }
 // ... and does: the weight sets are there (prepare_mixed_weights ran for this layer)
 bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
