@@ -51,5 +51,6 @@ done
 python3 "$R/tools/roofline_check.py" "$O/${RD}_bench_batch256_kernel_stats.csv" "$O/${RD}_bench.json" > "$O/${RD}_roofline_check.txt" 2>&1 || echo "roofline_check: DISAGREEMENT (see ${RD}_roofline_check.txt)"
 rocprofv3 --kernel-trace --stats -d "$O/proft" -o p --output-format csv -- python3 "$R/bench.py" --workload train --steps 5 --warmup 2 --no-roofline > "$O/${RD}_train_step_under_rocprof.json" 2>/dev/null || true
 cp -- "$O/proft/p_kernel_stats.csv" "$O/${RD}_train_step_kernel_stats.csv" || true
+python3 "$R/tools/roofline_check.py" --train "$O/${RD}_train_step_kernel_stats.csv" "$O/${RD}_train_step.json" >> "$O/${RD}_roofline_check.txt" 2>&1 || echo "roofline_check --train: DISAGREEMENT (see ${RD}_roofline_check.txt)"
 rm -rf -- "$O/proft"
 ls -la -- "$O"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Recompute bench.py's roofline block for the dominant kernel from the committed rocprofv3 summary and a layer table.
-    python tools/roofline_check.py profiles/r04_bench_batch256_kernel_stats.csv profiles/r04_bench.json [--tol 0.03]
+    python tools/roofline_check.py profiles/r05_bench_batch256_kernel_stats.csv profiles/r05_bench.json [--tol 0.03]
+    python tools/roofline_check.py --train profiles/r05_train_step_kernel_stats.csv profiles/r05_train_step.json
 Independent of the library: executed / useful FLOPs come from the layer shapes below (batch from the bench line),
 the average launch time from the rocprofv3 --kernel-trace --stats CSV.  Exits non-zero when a figure of the bench
 line disagrees by more than --tol.  (The bench line and the CSV are two runs of the same command on the same build.)"""
@@ -35,8 +36,35 @@ def pad(v, m):
     return (v + m - 1) // m * m
 
 
+def check_train(stats, bench, tol):
+    """--train: the training workload.  Independent figures from the rocprofv3 summary of `bench.py --workload train
+    --steps 5 --warmup 2 --no-roofline` (7 iterations = 7 k_stem launches): launches of the fused Winograd kernels per iteration, of
+    k_wgrad per iteration, and the pure kernel time of both classes, against `roofline.per_class` of the bench line (whose times are
+    hipEvent pairs that also contain the kernel boundary in front of each launch: they may exceed the CSV's by up to 8 %)."""
+    line = [l for l in open(bench) if l.startswith('{')][-1]
+    pc = json.loads(line)['roofline']['per_class']
+    rows = list(csv.DictReader(open(stats)))
+    iters = sum(int(r['Calls']) for r in rows if 'k_stem' in r['Name'])
+    bad = 0
+    print('%d iterations in %s' % (iters, stats))
+    print('%-22s %14s %14s %14s %14s' % ('class', 'launches (csv)', 'launches (line)', 'ms (csv)', 'ms (line)'))
+    # (class, kernels counted as its launches, kernels whose time belongs to it: a k_wgrad scope also holds its split-K reduction)
+    for cls, pat, tpat, slack in (('wino_fused', 'k_wino_fused', 'k_wino_fused', 0.08), ('wgrad', 'k_wgrad<', 'k_wgrad', 0.08)):
+        sel = [r for r in rows if pat in r['Name']]
+        calls = sum(int(r['Calls']) for r in sel)
+        ms = sum(int(r['TotalDurationNs']) for r in rows if tpat in r['Name']) / iters / 1e6
+        lp, mp = pc[cls]['launches_per_step'], pc[cls]['ms_per_step']
+        ok = calls == lp * iters and 0 <= (mp - ms) / ms <= max(tol, slack)
+        bad += not ok
+        print('%-22s %14.1f %14d %14.3f %14.3f%s' % (cls, calls / iters, lp, ms, mp, '' if ok else '   <-- DISAGREES'))
+    sys.exit(1 if bad else 0)
+
+
 def main():
     tol = float(sys.argv[sys.argv.index('--tol') + 1]) if '--tol' in sys.argv else 0.03
+    if '--train' in sys.argv:
+        args = [a for a in sys.argv[1:] if not a.startswith('--') and a != str(tol)]
+        return check_train(args[0], args[1], tol)
     stats, bench = sys.argv[1], sys.argv[2]
     line = [l for l in open(bench) if l.startswith('{')][-1]
     b = json.loads(line)
