@@ -438,6 +438,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
         f.cout_pad = L.cout_pad; f.cout_store = c.cout_store; f.out_pitch = c.out_pitch; f.out_coff = c.out_coff;
         f.res_pitch = c.res_pitch; f.border_bias = L.border; f.flags = c.flags;
+        f.xcd_pairs = h->opt.wm_xcdpairs ? 1 : 0;
         double fexec = 0.0, fuse = 0.0;
         for (int tau = 0; tau < 4; ++tau) {
             const int nr = tau >= 2 ? g.n3 : g.n4, nc = (tau & 1) ? g.n3 : g.n4;
@@ -447,7 +448,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         }
 #ifdef FFR_TRACE
         if (h->opt.wf_trace) {      // diagnostics: per-block phase stamps and which CU ran which tile types, printed after a stream sync
-            const int nbm = wino_mixed_blocks_launched(c.N, c.H, c.W, L.cout_pad);
+            const int nbm = wino_mixed_blocks_launched(c.N, c.H, c.W, L.cout_pad, f.xcd_pairs);
             unsigned long long* dbuf = nullptr;
             HIPCK(h, hipMalloc((void**)&dbuf, (size_t)nbm * 12 * sizeof(unsigned long long)));
             HIPCK(h, hipMemsetAsync(dbuf, 0, (size_t)nbm * 12 * sizeof(unsigned long long), st));
@@ -591,7 +592,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             // block -> tile mapping: the channel groups of a tile group next to each other on ONE XCD (V is fetched into that
             // L2 once instead of once per channel group: 59.5 -> 45.7 GB fetched + written per forward, 17.53 -> 17.32 ms at
             // batch 256); option wf_mapv = 0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
-            f.map_v = h->opt.wf_mapv ? 1 : 0;
+            f.map_v = h->opt.wf_mapv ? (phased ? (h->opt.wf_mapx ? 2 : 1) : (h->opt.wf_maph && nbn >= 4 && nbn % 2 == 0 ? 3 : 1)) : 0;
             f.half_n = half_n ? 1 : 0;
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
@@ -1422,7 +1423,7 @@ const OptEntry OPTIONS[] = {
     {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
     {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1},
     {"wf_mixed", &Options::wf_mixed, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
-    {"channel_rows", &Options::channel_rows, nullptr, 0, 4},
+    {"channel_rows", &Options::channel_rows, nullptr, 0, 4}, {"wm_xcdpairs", &Options::wm_xcdpairs, nullptr, 0, 1}, {"wf_mapx", &Options::wf_mapx, nullptr, 0, 1}, {"wf_maph", &Options::wf_maph, nullptr, 0, 1},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {

@@ -65,6 +65,9 @@ struct Options {
     int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
     int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
     int wf_mixed = 1;             // 1: 14x14 maps are tiled 4+4+3+3 (k_wino_fused_mixed) when the launch gives every CU two blocks or more
+    int wf_maph = 0;              // (measured round 5: <0,2> fetches 5.23 -> 4.25 GB per step, the forward 15.25 vs 15.19 ms: off) V-fed k_wino_fused with >= 4 channel groups: the two XCD quads split the channel groups (half of U per L2, V read twice)
+    int wf_mapx = 1;              // k_wino_fused with the in-kernel input transform: an XCD owns a contiguous range of tile groups (halo rows shared in its L2)
+    int wm_xcdpairs = 1;          // k_wino_fused_mixed: XCDs specialise in pairs of tile types (round 5)
     int channel_rows = 0;         // k_channel_path: blocks per image (1, 2, 4); 0 = from the batch and the CU count (round 5)
     int igemm_tile64 = 0;         // > 0: tile shape forced for large direct convolutions with 64 output channels (1..4, ffr_conv_desc.tile)
     int combine_v = 1;            // 1: a bottleneck's combine also writes V for the next conv1 when that runs k_wino_fused from V

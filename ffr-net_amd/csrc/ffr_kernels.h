@@ -119,6 +119,7 @@ struct WinoMixedArgs {
     int N, H, W, nkc;
     int cout_pad, cout_store, out_pitch, out_coff, res_pitch, border_bias, flags;
     WinoMixedGeom g;                        // filled by the launcher, as everything below
+    int xcd_pairs;                          // in: 1 = XCDs 0-3 run the tile types (4,4) + (3,3), XCDs 4-7 (4,3) + (3,4) (two weight sets per L2 instead of four)
     int mbn[4], boff[4], nbn, tpi_off[4], tpi_total;
     long long T[4];
     unsigned long long* trace;              // diagnostics (-DFFR_TRACE build, option "wf_trace"): 12 words per block, or null
@@ -129,7 +130,7 @@ int wino_mixed_xp(int tau);
 size_t wino_mixed_v_floats(const WinoMixedGeom& g, int N, int cin_pad, size_t off[4]);
 int wino_mixed_blocks(int N, int H, int W, int cout_pad);
 size_t wino_mixed_u_floats(int tau, int cout_pad, int cin_pad);
-int wino_mixed_blocks_launched(int N, int H, int W, int cout_pad);
+int wino_mixed_blocks_launched(int N, int H, int W, int cout_pad, int xcd_pairs);
 hipError_t launch_wino_weights_mixed(const float* w, float* um, int cout_pad, int cin_pad, int tau, hipStream_t stream);
 hipError_t wino_mixed_init();
 hipError_t launch_wino_in_mixed(const float* x, float* V, int N, int H, int W, int pitch, int cin_pad, hipStream_t stream);

@@ -229,7 +229,18 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // slice of U stays in the L2, V is re-read by the XCD of every channel group).  Speed only.
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     int nb, mb;
-    if (a.map_v) {          // all channel groups of a tile group on one XCD, next to each other in dispatch order
+    if (a.map_v == 2) {     // as map_v == 1, and an XCD owns a CONTIGUOUS range of tile groups (round 5, launches that transform their own
+        // input): tile groups mb and mb + 1 cover neighbouring tile rows of the same image, whose 6x6 patches share two pixel rows of
+        // every six -- on one XCD that halo is fetched into the L2 once, with the round-robin map below twice (two XCDs)
+        nb = idx % a.nbn; mb = xcd * ((a.mbn + 7) >> 3) + idx / a.nbn;
+        if (idx / a.nbn >= ((a.mbn + 7) >> 3)) return;
+    } else if (a.map_v == 3) {
+        // round 5, V-fed launches with many channel groups (nbn even, >= 4): XCDs 0-3 take the lower half of the channel groups, XCDs 4-7
+        // the upper half; a tile group is processed by one XCD of each quad.  Every L2 then streams HALF of U per launch and V is
+        // read by two XCDs instead of one: for cin = cout = 512 on 7x7 maps 151 + 150 MB instead of 302 + 75 MB.
+        const int hn = a.nbn >> 1;
+        nb = (xcd >> 2) * hn + idx % hn; mb = (idx / hn) * 4 + (xcd & 3);
+    } else if (a.map_v) {   // all channel groups of a tile group on one XCD, next to each other in dispatch order
         nb = idx % a.nbn; mb = (idx / a.nbn) * 8 + xcd;
     } else if (a.nbn % 8 == 0) {
         const int r = a.nbn >> 3;
@@ -677,6 +688,7 @@ hipError_t wino_fused_init() {
 }
 
 static int wf_grid(int mbn, int nbn, int map_v) {      // inverse of the block decoding in k_wino_fused
+    if (map_v == 3) return (mbn + 3) / 4 * 8 * (nbn >> 1);
     if (map_v) return (mbn + 7) / 8 * 8 * nbn;
     if (nbn % 8 == 0) return mbn * nbn;
     if (8 % nbn == 0) { const int per = 8 / nbn; return 8 * ((mbn + per - 1) / per); }

@@ -485,10 +485,24 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused_mixed(const WinoMixedArgs
     // blocks ordered by type: [ (4,4) | (4,3) | (3,4) | (3,3) ]; inside a type the map of k_wino_fused (the channel groups of a tile
     // group next to each other on one XCD)
     const int b = blockIdx.x;
-    const int tau = b >= a.boff[2] ? (b >= a.boff[3] ? 3 : 2) : (b >= a.boff[1] ? 1 : 0);
-    const int bl = b - a.boff[tau];
-    const int xcd = bl & 7, idx = bl >> 3;
-    const int nb = idx % a.nbn, mb = (idx / a.nbn) * 8 + xcd;
+    int tau, nb, mb;
+    if (a.xcd_pairs) {
+        // Round 5: the XCDs specialise in PAIRS of tile types.  Blocks b and b + 8 share an XCD (round-robin dispatch); XCDs 0-3 run
+        // (4,4) in the first half of the grid and (3,3) in the second, XCDs 4-7 run (4,3) then (3,4): every CU still pairs a long block
+        // with a short one (9 + 7 = 8 + 8 slots), but an XCD's L2 streams TWO weight sets per launch instead of four (268 -> 134 MB of
+        // the 405 MB a 256 -> 256 launch fetched: every XCD read all four sets once).  Inside a type: tile groups round-robin over the
+        // four XCDs of its pair, the channel groups of a tile group next to each other on one XCD (V from that L2).
+        const int half = b >= a.boff[1];                    // boff[1] = blocks of the first half (a multiple of 8)
+        const int bl = b - (half ? a.boff[1] : 0);
+        const int xcd = bl & 7, idx = bl >> 3;
+        tau = xcd < 4 ? (half ? 3 : 0) : (half ? 2 : 1);
+        nb = idx % a.nbn; mb = (idx / a.nbn) * 4 + (xcd & 3);
+    } else {
+        tau = b >= a.boff[2] ? (b >= a.boff[3] ? 3 : 2) : (b >= a.boff[1] ? 1 : 0);
+        const int bl = b - a.boff[tau];
+        const int xcd = bl & 7, idx = bl >> 3;
+        nb = idx % a.nbn; mb = (idx / a.nbn) * 8 + xcd;
+    }
     if (mb >= a.mbn[tau]) return;
     switch (tau) {
         case 0: fused_mixed_body<4, 4>(a, 0, mb, nb, smem); break;
@@ -521,19 +535,28 @@ hipError_t launch_wino_fused_mixed(WinoMixedArgs a, hipStream_t stream) {
         tpi += nr * nc;
     }
     a.tpi_total = tpi;
+    if (a.xcd_pairs) {
+        // every type has the same number of tile groups on a square map (n4 * n3 tiles per image each way): two halves of
+        // 8 * ceil(groups / 4) * nbn blocks
+        int gmax = 0;
+        for (int tau = 0; tau < 4; ++tau) gmax = a.mbn[tau] > gmax ? a.mbn[tau] : gmax;
+        const int half = (gmax + 3) / 4 * 8 * a.nbn;
+        a.boff[0] = 0; a.boff[1] = half; a.boff[2] = half; a.boff[3] = half;
+        tot = 2 * half;
+    }
     hipLaunchKernelGGL(k_wino_fused_mixed, dim3(tot), dim3(256), WM_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
 // grid size of launch_wino_fused_mixed (tile groups rounded up to 8 per type for the XCD-aware map)
-int wino_mixed_blocks_launched(int N, int H, int W, int cout_pad) {
+int wino_mixed_blocks_launched(int N, int H, int W, int cout_pad, int xcd_pairs) {
     WinoMixedGeom g;
     if (!wino_mixed_geom(H, W, &g)) return 0;
     long long T[4]; int groups[4];
     wino_mixed_counts(g, N, T, groups);
-    int tot = 0;
-    for (int tau = 0; tau < 4; ++tau) tot += (groups[tau] + 7) / 8 * 8 * (cout_pad / 64);
-    return tot;
+    int tot = 0, gmax = 0;
+    for (int tau = 0; tau < 4; ++tau) { tot += (groups[tau] + 7) / 8 * 8 * (cout_pad / 64); gmax = groups[tau] > gmax ? groups[tau] : gmax; }
+    return xcd_pairs ? 2 * ((gmax + 3) / 4 * 8 * (cout_pad / 64)) : tot;
 }
 
 size_t wino_mixed_u_floats(int tau, int cout_pad, int cin_pad) { return (size_t)(cout_pad / 64) * (cin_pad / 8) * wino_mixed_xp(tau) * 512; }

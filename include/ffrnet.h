@@ -182,6 +182,12 @@ int ffr_profile_enable(ffr_handle* h, int on);
  *                         first time a launch is eligible (ffr_memory_stats reports their bytes and seconds)
  *   "igemm_tile64" (0)    1..4: tile shape forced for the large direct convolutions with 64 output channels (ignored where the
  *                         tile's width does not divide the padded channel count)
+ *   "wm_xcdpairs" (1)     k_wino_fused_mixed: XCDs 0-3 run the tile types (4,4) + (3,3), XCDs 4-7 (4,3) + (3,4): two weight sets per L2 and
+ *                         launch instead of four (12.7 -> 9.2 GB fetched per forward, -0.6 % time); 0: every XCD runs all four types
+ *   "wf_mapx" (1)         k_wino_fused with the in-kernel input transform: an XCD owns a contiguous range of tile groups, so the
+ *                         halo rows neighbouring tile rows share are fetched into one L2 (7.7 -> 6.6 GB per forward); 0: round-robin
+ *   "wf_maph" (0)         V-fed k_wino_fused with >= 4 channel groups: the two XCD quads split the channel groups (half of U per L2, V
+ *                         read twice: 5.2 -> 4.2 GB per forward, but 15.25 vs 15.19 ms: off)
  *   "channel_rows" (0)    k_channel_path (RecNet's channel branch): 1 / 2 / 4 blocks per image (128 CT rows of M_channel each);
  *                         0 = chosen from the batch and the CU count (fewer images than CUs -> more blocks per image)
  *   "combine_v" (1)       1: a bottleneck's combine (res * scale + shortcut) also writes the Winograd transform V of its

@@ -327,6 +327,13 @@ def test_mixed_tile_sizes_match_direct_and_torch(engine, case):
     assert rel(got_d, ref) < OP_TOL
     assert rel(got_m, ref) < 1e-4 and rel(got_m, got_d) < 1e-4 and rel(got_m, got_4) < 1e-4
     assert not torch.equal(got_m, got_4)            # it really is another arithmetic
+    # the block -> (tile type, XCD) map is speed only: every XCD running all four types (round 4) gives the same bits
+    engine.set_option('wm_xcdpairs', 0)
+    try:
+        got_m0 = engine.op_conv3x3(x.cuda(), w, bias, slope, 0, 4, rd).permute(0, 3, 1, 2).cpu()
+    finally:
+        engine.set_option('wm_xcdpairs', 1)
+    assert torch.equal(got_m0, got_m)
 
 
 @pytest.mark.gpu
@@ -844,6 +851,7 @@ def test_experiment_knobs_keep_parity(tmp_path):
                         ('phased256', {'FFR_OPT_WF_PHASED_MAXK': '256'}), ('direct', {'FFR_OPT_WINO': '0'}),
                         ('nohalf', {'FFR_OPT_WF_HALFBLOCKS': '0'}), ('nocombinev', {'FFR_OPT_COMBINE_V': '0'}),
                         ('minblocks0', {'FFR_OPT_WF_MINBLOCKS': '0'}), ('nomixed', {'FFR_OPT_WF_MIXED': '0'}),
+                        ('noxcdpairs', {'FFR_OPT_WM_XCDPAIRS': '0'}), ('nomapx', {'FFR_OPT_WF_MAPX': '0'}), ('maph', {'FFR_OPT_WF_MAPH': '1'}),
                         ('chrows1', {'FFR_OPT_CHANNEL_ROWS': '1'}), ('chrows2', {'FFR_OPT_CHANNEL_ROWS': '2'}), ('chrows4', {'FFR_OPT_CHANNEL_ROWS': '4'}),
                         ('tile64', {'FFR_OPT_IGEMM_TILE64': '4'})):
         got = run(name, **knobs)
