@@ -43,7 +43,7 @@ struct TScratch {
     float* canvas = nullptr; size_t canvas_floats = 0;   // dy embedded in a zero-bordered map (8x8, Winograd data gradient)
     float* edgeA = nullptr; size_t edgeA_floats = 0;     // gathered operands of the bottom-row / right-column GEMMs
     float* edgeW = nullptr; size_t edgeW_floats = 0;     // their weights
-    float* edgeO = nullptr; size_t edgeO_floats = 0;     // their outputs [imgs*9 + imgs*8][need_pad]
+    float* edgeO = nullptr; size_t edgeO_floats = 0;     // their outputs [2][imgs*9][need_pad] (the column GEMM uses imgs*8 of its rows)
     bool wino = true;   // ffr_train_option("winograd")
     int fused = 1;      // ffr_train_option("fused"): 1 = Winograd launches that fill the chip run k_wino_fused on the live weights, 2 = all of them (tests), 0 = none
     bool fold = true;                              // ffr_train_option("fold_channel")
@@ -52,6 +52,10 @@ struct TScratch {
 int gemm_rows(ffr_handle* h, const Work& w, const float* A, int a_pitch, int K_pad, const float* W, const float* bias,
               int N_pad, float* out, int out_pitch, long long rows, const float* resid, int res_pitch, int flags,
               hipStream_t st);
+
+int gemm_batched(ffr_handle* h, const Work& w, const float* A, long long a_bstride, int K_pad, const float* W,
+                 long long w_bstride, int N_pad, float* out, int out_pitch, long long out_bstride, int M, int nbatch,
+                 hipStream_t st);
 
 void conv_call_common(ConvCall& c, const Work& w, bool wino = false) {
     c.partial = w.partial; c.partial_cap = w.partial_cap; c.tickets = w.tickets; c.tickets_cap = w.tickets_cap;
@@ -138,8 +142,8 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
     c.out = s.dxp; c.out_pitch = need_pad; c.out_coff = 0; c.cout_store = need_pad;
     const int imgs = G * N;
     const bool wino = s.wino && L.cout_pad >= 128 && s.U && (size_t)36 * need_pad * L.cout_pad <= s.U_floats &&
-                      (size_t)imgs * 64 * L.cout_pad <= s.canvas_floats && (size_t)imgs * 17 * 3 * L.cout_pad <= s.edgeA_floats &&
-                      (size_t)2 * need_pad * 3 * L.cout_pad <= s.edgeW_floats && (size_t)imgs * 17 * need_pad <= s.edgeO_floats;
+                      (size_t)imgs * 64 * L.cout_pad <= s.canvas_floats && (size_t)imgs * 18 * 3 * L.cout_pad <= s.edgeA_floats &&
+                      (size_t)2 * need_pad * 3 * L.cout_pad <= s.edgeW_floats && (size_t)imgs * 18 * need_pad <= s.edgeO_floats;
     if (wino) {
         // The 9x9 padded gradient in three pieces: rows/columns 0..7 as the 'same' F(4x4,3x3) convolution of dy embedded at
         // (1,1) of an 8x8 map (2x2 tiles instead of the 3x3 a 9x9 output would need), row 8 and column 8 (only the last
@@ -161,8 +165,11 @@ int layer_backward(ffr_handle* h, const Work& w, const TLayer& L, const TSaved& 
         float* Or = s.edgeO + (size_t)imgs * 9 * need_pad;
         TLAUNCH(FFR_KC_TRAIN_XFORM, launch_dgrad_edges(s.dy, Eb, Er, imgs, L.cout_pad, st));
         TLAUNCH(FFR_KC_TRAIN_XFORM, launch_pack_dgrad_edges(L.w, L.cout_pad, L.cin_pad, Wb, Wr, need_pad, st));
-        RC(gemm_rows(h, w, Eb, 3 * L.cout_pad, 3 * L.cout_pad, Wb, nullptr, need_pad, Ob, need_pad, (long long)imgs * 9, nullptr, 0, 0, st));
-        RC(gemm_rows(h, w, Er, 3 * L.cout_pad, 3 * L.cout_pad, Wr, nullptr, need_pad, Or, need_pad, (long long)imgs * 8, nullptr, 0, 0, st));
+        // row 8 and column 8 as ONE batched launch of two GEMMs (round 5: each fills 144 .. 288 of the chip's 768 tile slots by itself;
+        // the column GEMM runs with imgs * 9 rows like the row GEMM -- its last imgs rows read scratch and land in rows nobody reads)
+        (void)Wr; (void)Er;
+        RC(gemm_batched(h, w, Eb, (long long)imgs * 9 * 3 * L.cout_pad, 3 * L.cout_pad, Wb, (long long)need_pad * 3 * L.cout_pad, need_pad, Ob, need_pad,
+                        (long long)imgs * 9 * need_pad, imgs * 9, 2, st));
         TLAUNCH(FFR_KC_TRAIN_XFORM, launch_fold_reflect3(s.dxp, Ob, Or, need_pad, imgs, round_up(cin_need, 4), add, add_pitch, add_coff, dx, dx_pitch,
                                       dx_coff, st));
         return FFR_OK;
@@ -401,9 +408,9 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->sc.slab_floats = (size_t)4 * 512 * 9 * 1536; t->sc.slabs = a.take(t->sc.slab_floats);
         t->sc.U_floats = (size_t)36 * 512 * 1536; t->sc.U = a.take(t->sc.U_floats);
         t->sc.canvas_floats = imgs * 64 * 512; t->sc.canvas = a.take(t->sc.canvas_floats);
-        t->sc.edgeA_floats = imgs * 17 * 3 * 512; t->sc.edgeA = a.take(t->sc.edgeA_floats);
+        t->sc.edgeA_floats = imgs * 18 * 3 * 512; t->sc.edgeA = a.take(t->sc.edgeA_floats);
         t->sc.edgeW_floats = (size_t)2 * 1024 * 3 * 512; t->sc.edgeW = a.take(t->sc.edgeW_floats);
-        t->sc.edgeO_floats = imgs * 17 * 1024; t->sc.edgeO = a.take(t->sc.edgeO_floats);
+        t->sc.edgeO_floats = imgs * 18 * 1024; t->sc.edgeO = a.take(t->sc.edgeO_floats);
         t->dFeatNew = a.take(rows * 512); t->d512a = a.take(rows * 512); t->d512b = a.take(rows * 512);
         t->dBufM = a.take(rows * 1024); t->extM = a.take(rows * 1024); t->dF = a.take(rows * 1024);
         t->d256a = a.take(rows * 256); t->d256b = a.take(rows * 256); t->d256c = a.take(rows * 256); t->dms = a.take(rows * 64);
@@ -720,9 +727,9 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
     s.slab_floats = (size_t)16 * wp.size(); RC(dev_alloc_t(h, own, s.slab_floats, &s.slabs));
     s.U_floats = (size_t)36 * L.cout_pad * (L.cin_pad > need_pad ? L.cin_pad : need_pad); RC(dev_alloc_t(h, own, s.U_floats, &s.U));
     s.canvas_floats = (size_t)G * N * 64 * L.cout_pad; RC(dev_alloc_t(h, own, s.canvas_floats, &s.canvas));
-    s.edgeA_floats = (size_t)G * N * 17 * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeA_floats, &s.edgeA));
+    s.edgeA_floats = (size_t)G * N * 18 * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeA_floats, &s.edgeA));
     s.edgeW_floats = (size_t)2 * need_pad * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeW_floats, &s.edgeW));
-    s.edgeO_floats = (size_t)G * N * 17 * need_pad; RC(dev_alloc_t(h, own, s.edgeO_floats, &s.edgeO));
+    s.edgeO_floats = (size_t)G * N * 18 * need_pad; RC(dev_alloc_t(h, own, s.edgeO_floats, &s.edgeO));
     RC(layer_forward(h, w, L, sv, G, N, nullptr, 0, out_nhwc, L.cout_pad, 0, 0, true, s, st));
     RC(layer_backward(h, w, L, sv, G, N, da_nhwc, L.cout_pad, 0, 0, s, dx_nhwc, L.cin_pad, 0, cin, nullptr, 0, 0, st));
     if (dw_packed) HIPCK(h, hipMemcpyAsync(dw_packed, L.gw, wp.size() * 4, hipMemcpyDeviceToDevice, st));
