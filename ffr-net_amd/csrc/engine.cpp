@@ -240,16 +240,25 @@ int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner) {
     if (!L.wuc || !L.w) return fail(h, FFR_ERR_STATE, "mixed-tile weights asked for a layer without Winograd weights");
     float* um[4] = {L.wuc, nullptr, nullptr, nullptr};
     const auto t0 = std::chrono::steady_clock::now();
+    size_t total = 0;
     for (int tau = 1; tau < 4; ++tau) {
         void* p = nullptr;
         const size_t bytes = wino_mixed_u_floats(tau, L.cout_pad, L.cin_pad) * sizeof(float);
-        if (hipMalloc(&p, bytes) != hipSuccess) return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu mixed-tile weight bytes failed", bytes);
-        owner.push_back(p);
-        um[tau] = (float*)p;
-        HIPCK(h, launch_wino_weights_mixed(L.w, um[tau], L.cout_pad, L.cin_pad, tau, nullptr));
-        if (&owner == &h->enc_allocs) { h->mixed_weight_bytes += bytes; h->enc_weight_bytes += bytes; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) {
+            um[tau] = (float*)p;
+            e = launch_wino_weights_mixed(L.w, um[tau], L.cout_pad, L.cin_pad, tau, nullptr);
+        }
+        if (e != hipSuccess) {          // nothing half-built stays behind: the layer keeps running on padded tiles
+            hipDeviceSynchronize();
+            for (int k = 1; k <= tau; ++k) if (um[k]) hipFree(um[k]);
+            return fail(h, e == hipErrorOutOfMemory ? FFR_ERR_NOMEM : FFR_ERR_HIP, "mixed-tile weights (%zu bytes): %s", bytes, hipGetErrorString(e));
+        }
+        total += bytes;
     }
     HIPCK(h, hipDeviceSynchronize());
+    for (int tau = 1; tau < 4; ++tau) owner.push_back(um[tau]);
+    if (&owner == &h->enc_allocs) { h->mixed_weight_bytes += total; h->enc_weight_bytes += total; }
     h->mixed_pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (int tau = 0; tau < 4; ++tau) L.wum[tau] = um[tau];
     return FFR_OK;
