@@ -433,7 +433,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // The first NPRE patch values of a phase (its first columns) are requested under the LAST K chunk of the phase before
     // (its weight-fragment slots are dying there), so the memory latency of a phase's first access (~2.5k cycles from HBM)
     // is paid under MFMAs and the column passes start at once.
-    constexpr int NPRE = 16;
+#ifndef FFR_WF_NPRE
+#define FFR_WF_NPRE 16          // tools/npre_experiment.py builds 24 / 32 for comparison (round 5: see DESIGN.md 3.2)
+#endif
+    constexpr int NPRE = FFR_WF_NPRE;
     f32x4 pre[NPRE];
     auto load_px = [&](int idx, unsigned so) {          // patch value idx = j * 6 + i (column-major)
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ro[idx % 6] + co[idx / 6], so, 0));
@@ -506,10 +509,10 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
                             if (j == 0) loadu(8, part, up);                                // xi 8 of this chunk
                             else if (c < 3) loadu(j - 1, part, up + 36 * 2048u);             // xi j-1 of the next chunk
                         }
-                        // last chunk: two patch values of the next phase per step take the place of the weight loads
-                        if (c == 3 && j >= 1 && 2 * (j - 1) < NPRE) {
-                            pre[2 * (j - 1)] = load_px(2 * (j - 1), soff_next);
-                            pre[2 * (j - 1) + 1] = load_px(2 * (j - 1) + 1, soff_next);
+                        // last chunk: NPRE / 8 patch values of the next phase per step take the place of the weight loads
+                        if (c == 3 && j >= 1) {
+#pragma unroll
+                            for (int q = 0; q < NPRE / 8; ++q) pre[(NPRE / 8) * (j - 1) + q] = load_px((NPRE / 8) * (j - 1) + q, soff_next);
                         }
                     }
                     if (g == 2 * NT && has_next) reada(cur ^ 1, j == 8 ? c + 1 : c, j == 8 ? 0 : j + 1);
