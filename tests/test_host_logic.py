@@ -114,6 +114,26 @@ def test_integration_lists_the_sources():
     assert b'k_wino_fused_q' not in raw           # no such kernel in the embedded code object either
 
 
+def test_committed_profiles_agree_with_their_bench_lines():
+    """The round's committed measurement set is self-consistent: tools/roofline_check.py recomputes the roofline block of
+    profiles/r05_bench.json from the rocprofv3 summary next to it (launches, average launch time, executed / useful FLOPs from a layer
+    table, the three fractions) and the training classes of profiles/r05_train_step.json from theirs; and the PMC summary bench.py
+    would quote carries the hash of the same build as the bench line."""
+    import json
+    prof = os.path.join(ROOT, 'profiles')
+    for extra in ([], ['--train']):
+        stats = 'r05_train_step_kernel_stats.csv' if extra else 'r05_bench_batch256_kernel_stats.csv'
+        line = 'r05_train_step.json' if extra else 'r05_bench.json'
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'roofline_check.py')] + extra +
+                             [os.path.join(prof, stats), os.path.join(prof, line)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+    bench = json.loads([l for l in open(os.path.join(prof, 'r05_bench.json')) if l.startswith('{')][-1])
+    pmc = json.load(open(os.path.join(prof, 'r05_pmc_hbm_traffic.json')))
+    assert pmc['so_sha256'] == bench['roofline']['so_sha256'] and pmc['batch'] == 256
+    assert abs(bench['roofline']['traffic_ratio_vs_compulsory'] - pmc['gb_per_step'] / (14.3 + 0.2732)) < 0.01
+    assert bench['secondary'][-1]['unit'] == 'pairs/s' and bench['secondary'][-1]['ms_per_iteration'] > 0       # the training line (VERDICT r04 #2)
+
+
 def test_weight_cache_sees_submodule_surgery():
     """replacing a Parameter / buffer on a SUB-module must invalidate the packed native copy.  The
     signature the shells compare on every forward is (identity, version) of each tensor in the tree."""
