@@ -202,7 +202,7 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
         return (double)bt / (double)(full + h->num_cus);
     };
     bool half_n = false;
-    if (h->opt.wf_halfblocks && !phased) {
+    if (!phased) {
         if (bt_full < min_blocks) half_n = 2 * bt_full >= min_blocks;
         else half_n = 0.92 * fit(2 * bt_full) > fit(bt_full);       // a half block costs ~8 % more per unit of work
     }
@@ -234,9 +234,13 @@ bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W
 // The weights of the tile types (4,3), (3,4), (3,3) of one layer, derived ON THE DEVICE from its packed direct weights the first
 // time a launch is eligible (round 4 packed them on the host at load time for all 27 layers, 0.7 GB per handle, whether or not
 // a batch of >= 256 images ever arrived).  Synchronous (hipMalloc + three small kernels); never inside a stream capture: the
-// callers run it from ensure_arena / before the launch of an operator test.
-int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner) {
+// callers run it from the encoder entry points (ensure_arena_encoder) / before the launch of an operator test.
+// The sets are an OPTIMISATION: when the device cannot hold them the layer keeps running on padded F(4x4) tiles -- the failure
+// is logged once, remembered per layer (wum_gave_up: no retry on every forward) and is NOT an error of the call (`strict`, the
+// operator test that asks for this path by name, is the exception).
+int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner, bool strict) {
     if (L.wum[1]) return FFR_OK;
+    if (L.wum_gave_up && !strict) return FFR_OK;
     if (!L.wuc || !L.w) return fail(h, FFR_ERR_STATE, "mixed-tile weights asked for a layer without Winograd weights");
     float* um[4] = {L.wuc, nullptr, nullptr, nullptr};
     const auto t0 = std::chrono::steady_clock::now();
@@ -252,7 +256,15 @@ int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner) {
         if (e != hipSuccess) {          // nothing half-built stays behind: the layer keeps running on padded tiles
             hipDeviceSynchronize();
             for (int k = 1; k <= tau; ++k) if (um[k]) hipFree(um[k]);
-            return fail(h, e == hipErrorOutOfMemory ? FFR_ERR_NOMEM : FFR_ERR_HIP, "mixed-tile weights (%zu bytes): %s", bytes, hipGetErrorString(e));
+            (void)hipGetLastError();    // the failed hipMalloc must not surface in the next launch wrapper
+            if (strict) return fail(h, e == hipErrorOutOfMemory ? FFR_ERR_NOMEM : FFR_ERR_HIP, "mixed-tile weights (%zu bytes): %s", bytes, hipGetErrorString(e));
+            L.wum_gave_up = true;
+            if (!h->mixed_gave_up_logged) {
+                h->mixed_gave_up_logged = true;
+                fprintf(stderr, "ffrnet: no room for the exact-tiling weight sets (%zu bytes: %s); the layers concerned stay on padded F(4x4) tiles\n",
+                        bytes, hipGetErrorString(e));
+            }
+            return FFR_OK;
         }
         total += bytes;
     }
@@ -265,13 +277,18 @@ int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner) {
 }
 
 // Every encoder convolution that a forward of N images of H x W would run on the exact tiling gets its weight sets now.
+// Called from the ENCODER entry points only (ffr_reserve, ffr_encoder_forward, ffr_embed*, ffr_encoder_trunk_nhwc, the training
+// iteration) with the real input size: the walk below maps blocks to map sizes from (H, W), which an operator call's arena
+// size says nothing about.  Readiness is per layer (wum[1] / wum_gave_up), so alternating input shapes cost one walk of 48
+// comparisons each and never a second derivation; (mixed_ready_*) only shortcuts the repeated same-shape forward.
+// Capture: a stream capture of ffr_embed is safe once ffr_reserve (or one eager forward) ran with the same N, H, W and options.
 int prepare_mixed_weights(ffr_handle* h, int N, int H, int W, size_t wino_cap) {
     if (!h->enc_loaded || !h->opt.wf_mixed || !h->opt.wino || !h->opt.wino_fused) return FFR_OK;
     if (h->mixed_ready_n >= N && h->mixed_ready_h == H && h->mixed_ready_w == W) return FFR_OK;     // the common case: one comparison per forward
     int ch = H, cw = W;
     for (Block& b : h->blocks) {
-        if (wino_mixed_eligible(h, b.c1, N, ch, cw, b.cin, wino_cap, -1)) RC(ensure_mixed_weights(h, b.c1, h->enc_allocs));
-        if (b.stride == 1 && wino_mixed_eligible(h, b.c2, N, ch, cw, b.depth, wino_cap, -1)) RC(ensure_mixed_weights(h, b.c2, h->enc_allocs));
+        if (wino_mixed_eligible(h, b.c1, N, ch, cw, b.cin, wino_cap, -1)) RC(ensure_mixed_weights(h, b.c1, h->enc_allocs, false));
+        if (b.stride == 1 && wino_mixed_eligible(h, b.c2, N, ch, cw, b.depth, wino_cap, -1)) RC(ensure_mixed_weights(h, b.c2, h->enc_allocs, false));
         ch /= b.stride; cw /= b.stride;
     }
     h->mixed_ready_n = N; h->mixed_ready_h = H; h->mixed_ready_w = W;
@@ -352,14 +369,10 @@ void plan_conv(long long M, int cout_pad, int nkt, int nbatch, int force_tile, i
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse) {
     int tile, nblocks;
     int force = c.tile;
-    if (!force && a.cout_pad == 64 && a.nbatch == 1 && a.M >= 65536 && a.nkt >= 9) force = h->opt.igemm_tile64;   // A/B knob
     if (force) {      // a forced tile whose width does not divide cout_pad would launch zero column tiles and leave `out` unwritten
         int fbm, fbn;
         igemm_tile_shape(force, &fbm, &fbn);
-        if (a.cout_pad % fbn) {
-            if (c.tile) return fail(h, FFR_ERR_ARG, "conv: forced tile %d (%d x %d) does not divide cout_pad %d", force, fbm, fbn, a.cout_pad);
-            force = 0;      // the igemm_tile64 knob: ignored where it does not fit
-        }
+        if (a.cout_pad % fbn) return fail(h, FFR_ERR_ARG, "conv: forced tile %d (%d x %d) does not divide cout_pad %d", force, fbm, fbn, a.cout_pad);
     }
     plan_conv(a.M, a.cout_pad, a.nkt, a.nbatch, force, h->opt.sk_minunits, &tile, &nblocks, &a.granule);
     int bm, bn;
@@ -447,7 +460,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         f.N = c.N; f.H = c.H; f.W = c.W; f.nkc = L.cin_pad / 8;
         f.cout_pad = L.cout_pad; f.cout_store = c.cout_store; f.out_pitch = c.out_pitch; f.out_coff = c.out_coff;
         f.res_pitch = c.res_pitch; f.border_bias = L.border; f.flags = c.flags;
-        f.xcd_pairs = h->opt.wm_xcdpairs ? 1 : 0;
+        f.xcd_pairs = 1;       // XCDs specialise in pairs of tile types (round 5; the uniform map measured slower: EXPERIMENTS.md)
         double fexec = 0.0, fuse = 0.0;
         for (int tau = 0; tau < 4; ++tau) {
             const int nr = tau >= 2 ? g.n3 : g.n4, nc = (tau & 1) ? g.n3 : g.n4;
@@ -600,8 +613,9 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
             f.Vc = phased ? nullptr : c.winoV; f.x = c.x; f.x_bytes = phased ? (unsigned)x_bytes : 0u; f.in_pitch = c.in_pitch; f.pad_mode = L.pad_mode;
             // block -> tile mapping: the channel groups of a tile group next to each other on ONE XCD (V is fetched into that
             // L2 once instead of once per channel group: 59.5 -> 45.7 GB fetched + written per forward, 17.53 -> 17.32 ms at
-            // batch 256); option wf_mapv = 0: one channel group per XCD (U stays in its L2, V is re-read by every group's XCD)
-            f.map_v = h->opt.wf_mapv ? (phased ? (h->opt.wf_mapx ? 2 : 1) : (h->opt.wf_maph && nbn >= 4 && nbn % 2 == 0 ? 3 : 1)) : 0;
+            // batch 256); with the in-kernel transform an XCD owns a contiguous range of tile groups (halo rows shared in its L2).
+            // The alternatives (one channel group per XCD; XCD quads splitting the channel groups) measured slower: EXPERIMENTS.md
+            f.map_v = phased ? 2 : 1;
             f.half_n = half_n ? 1 : 0;
             f.Uc = L.wuc; f.bias = L.bias; f.slope = L.slope; f.resid = c.resid; f.out = c.out;
             f.tile_sums = c.tile_sums;
@@ -658,13 +672,7 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
         if ((size_t)36 * T * L.cin_pad <= c.wino_cap && (size_t)36 * T * L.cout_pad <= c.wino_cap && T < 0x7fffffffLL) {
             // sub-batches: V and M of one slice (36 * tiles * channels * 4 B each) should stay in the
             // 256 MiB Infinity Cache between the transform that writes them and the kernel that reads them
-            const long long slice_mb = h->opt.wino_slice_mb;
-            int nslice = 1;
-            if (slice_mb > 0 && c.wino_stage == 0) {
-                const double mb = 36.0 * T * (L.cin_pad + L.cout_pad) * 4.0 / 1048576.0;
-                while (nslice < c.N && mb / nslice > (double)slice_mb) ++nslice;
-                while (c.N % nslice) ++nslice;
-            }
+            const int nslice = 1;       // (round 1 ran this path in Infinity-Cache-sized sub-batches: no gain once the fused kernel existed)
             const int Ns = c.N / nslice;
             const long long Ts = (long long)Ns * th * tw;
             for (int sl = 0; sl < nslice; ++sl) {
@@ -695,15 +703,6 @@ int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st) {
                         const double share = (double)((p + 255) / 256);
                         const double cost = rounds * bm * bn * share / (tt == IGEMM_TILE_128x128 ? 1.0 : 0.92);
                         if (cost < best) { best = cost; gtile = tt; gblocks = (int)p; }
-                    }
-                    const int force_gs = h->opt.gs_tile;
-                    if ((force_gs == IGEMM_TILE_128x128 && L.cout_pad % 128 == 0) || force_gs == IGEMM_TILE_128x64) {
-                        gtile = force_gs;
-                        int bm, bn;
-                        igemm_tile_shape(gtile, &bm, &bn);
-                        const long long tiles = 36LL * ((Ts + bm - 1) / bm) * (L.cout_pad / bn);
-                        const long long pmax = 256LL * igemm_resident_blocks(gtile);
-                        gblocks = (int)(pmax > tiles ? tiles : pmax);
                     }
                     GemmStreamArgs g{};
                     g.A = c.winoV; g.W = L.wu; g.C = c.winoM; g.M = (int)Ts; g.K = L.cin_pad; g.Npad = L.cout_pad; g.nbatch = 36;
@@ -761,8 +760,7 @@ Work layout(const Options& opt, char* base, int N, int H, int W) {
     {
         auto tiles = [&](int div) { return (size_t)N * ((H / div + 3) / 4) * ((W / div + 3) / 4); };
         size_t cap = 36 * tiles(2) * 128;                                   // 56x56, 64 -> 128 channels
-        const bool wino_112 = opt.wino_112 != 0;
-        if (wino_112 && 36 * tiles(1) * 64 > cap) cap = 36 * tiles(1) * 64;   // 112x112, 64 -> 64 (first bottleneck)
+        if (36 * tiles(1) * 64 > cap) cap = 36 * tiles(1) * 64;   // 112x112, 64 -> 64 (first bottleneck)
         if (36 * tiles(4) * 256 > cap) cap = 36 * tiles(4) * 256;           // 28x28, 128 -> 256
         if (36 * tiles(8) * 512 > cap) cap = 36 * tiles(8) * 512;           // 14x14, 256 -> 512
         if (36 * tiles(16) * 1536 > cap) cap = 36 * tiles(16) * 1536;       // 7x7, RecNet 1536 -> 512
@@ -812,6 +810,12 @@ int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w) {
     *w = layout(h->opt, h->arena, N, H, W);
     w->tickets = h->tickets;
     w->tickets_cap = h->tickets_cap;
+    return FFR_OK;
+}
+
+// ensure_arena for the calls that run the encoder on N images of H x W: also derives the exact-tiling weight sets those launches use
+int ensure_arena_encoder(ffr_handle* h, int N, int H, int W, Work* w) {
+    RC(ensure_arena(h, N, H, W, w));
     return prepare_mixed_weights(h, N, H, W, w->wino_cap);
 }
 
@@ -837,11 +841,10 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         c1.out = w.t1; c1.out_pitch = b.depth; c1.cout_store = b.depth;
         c1.partial = w.partial; c1.partial_cap = w.partial_cap; c1.tickets = w.tickets; c1.tickets_cap = w.tickets_cap; c1.winoV = w.winoV; c1.winoM = w.winoM; c1.wino_cap = w.wino_cap;
         // conv1 -> conv2 without the activation round trip when both run as Winograd on a map of <= 4x4 tiles
-        const bool oi_fuse = h->opt.wino_oi != 0;
         const long long Tt = (long long)N * ((ch + 3) / 4) * ((cw + 3) / 4);
         bool chained = false;
         const bool fused_on = h->opt.wino_fused != 0;
-        if (!fused_on && oi_fuse && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
+        if (!fused_on && b.stride == 1 && b.c1.wu && b.c2.wu && b.c1.cout_pad == b.c2.cin_pad && b.c2.pad_mode == 0 &&
             wino_out_in_supported(ch, cw, b.c1.cout_pad) && (size_t)36 * Tt * b.c1.cout_pad <= w.wino_cap &&
             (size_t)36 * Tt * b.c1.cin_pad <= w.wino_cap && (size_t)36 * Tt * b.c2.cout_pad <= w.wino_cap) {
             c1.wino_stage = 1; c1.took_wino = &chained;
@@ -860,9 +863,8 @@ int run_trunk(ffr_handle* h, const Work& w, const float* x_nchw, int N, int H, i
         // ([N][tiles][C], the layout k_se_fc reads); the direct path (stride 2, 64 channels) pools separately
         bool pooled = false;
         const int tiles = ((ho + 3) / 4) * ((wo + 3) / 4);
-        const bool se_fuse = h->opt.se_fuse != 0;
         const int se_maxtiles = h->opt.se_maxtiles;
-        if (b.fc1 && se_fuse && b.stride == 1 && tiles <= se_maxtiles && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
+        if (b.fc1 && b.stride == 1 && tiles <= se_maxtiles && (size_t)tiles * b.depth <= (size_t)32 * 512 && b.c2.cout_pad == b.depth) {
             c2.tile_sums = w.se_part; c2.tile_sums_written = &pooled;
         }
         if (chained) c2.wino_stage = 2;
@@ -1336,7 +1338,7 @@ size_t ffr_workspace_bytes(const ffr_handle* h, int N, int H, int W) {
 int ffr_reserve(ffr_handle* h, int N, int H, int W) {
     FFR_DEVICE_SCOPE(h); RC(check_fwd(h, false, false, N));
     Work w;
-    return ensure_arena(h, N, H, W, &w);
+    return ensure_arena_encoder(h, N, H, W, &w);
 }
 
 int ffr_encoder_forward(ffr_handle* h, const float* x, int N, int H, int W, float* featmap_nchw, float* f, void* stream) {
@@ -1346,7 +1348,7 @@ int ffr_encoder_forward(ffr_handle* h, const float* x, int N, int H, int W, floa
     if (f && (H != 112 || W != 112)) return fail(h, FFR_ERR_UNSUPPORTED, "f needs a 112x112 input (Linear(512*7*7,512))");
     hipStream_t st = (hipStream_t)stream;
     Work w;
-    RC(ensure_arena(h, N, H, W, &w));
+    RC(ensure_arena_encoder(h, N, H, W, &w));
     RC(run_encoder(h, w, x, N, H, W, featmap_nchw ? w.trunk_bn : nullptr, f, st));
     if (featmap_nchw) {
         Scope s(h, st, FFR_KC_LAYOUT, 0, 8.0 * N * (H / 16) * (W / 16) * 512);
@@ -1378,7 +1380,7 @@ int ffr_embed(ffr_handle* h, const float* x, int N, float* f_new, float* f, void
     if (!x || !f_new) return fail(h, FFR_ERR_ARG, "x / f_new is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;
-    RC(ensure_arena(h, N, 112, 112, &w));
+    RC(ensure_arena_encoder(h, N, 112, 112, &w));
     RC(run_encoder(h, w, x, N, 112, 112, w.X, f, st));
     return run_recnet(h, w, N, f_new, nullptr, st);
 }
@@ -1389,7 +1391,7 @@ int ffr_embed_u8(ffr_handle* h, const uint8_t* img_hwc_rgb, const uint8_t* flip,
     if (!img_hwc_rgb || !f_new) return fail(h, FFR_ERR_ARG, "img / f_new is null");
     hipStream_t st = (hipStream_t)stream;
     Work w;
-    RC(ensure_arena(h, N, 112, 112, &w));
+    RC(ensure_arena_encoder(h, N, 112, 112, &w));
     U8In u8{img_hwc_rgb, flip};
     RC(run_encoder(h, w, nullptr, N, 112, 112, w.X, f, st, &u8));
     return run_recnet(h, w, N, f_new, nullptr, st);
@@ -1423,16 +1425,12 @@ namespace {
 struct OptEntry { const char* name; int ffr_eng::Options::*i; long long ffr_eng::Options::*l; long long lo, hi; };
 const OptEntry OPTIONS[] = {
     {"wino", &Options::wino, nullptr, 0, 1}, {"wino_mincin", &Options::wino_mincin, nullptr, 0, 1 << 20},
-    {"wino_112", &Options::wino_112, nullptr, 0, 1}, {"wino_fused", &Options::wino_fused, nullptr, 0, 1},
+    {"wino_fused", &Options::wino_fused, nullptr, 0, 1},
     {"wf_phased_maxk", &Options::wf_phased_maxk, nullptr, 0, 1 << 20}, {"wf_minblocks", nullptr, &Options::wf_minblocks, 0, 1LL << 40},
-    {"wf_halfblocks", &Options::wf_halfblocks, nullptr, 0, 1},
     {"se_maxtiles", &Options::se_maxtiles, nullptr, 0, 1 << 20}, {"wf_tailsplit", &Options::wf_tailsplit, nullptr, 0, 1},
-    {"wf_mapv", &Options::wf_mapv, nullptr, 0, 1}, {"wino_slice_mb", nullptr, &Options::wino_slice_mb, 0, 1LL << 20},
-    {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"gs_tile", &Options::gs_tile, nullptr, 0, 2},
-    {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20}, {"wino_oi", &Options::wino_oi, nullptr, 0, 1},
-    {"se_fuse", &Options::se_fuse, nullptr, 0, 1}, {"combine_v", &Options::combine_v, nullptr, 0, 1},
-    {"wf_mixed", &Options::wf_mixed, nullptr, 0, 1}, {"igemm_tile64", &Options::igemm_tile64, nullptr, 0, 4},
-    {"channel_rows", &Options::channel_rows, nullptr, 0, 4}, {"wm_xcdpairs", &Options::wm_xcdpairs, nullptr, 0, 1}, {"wf_mapx", &Options::wf_mapx, nullptr, 0, 1}, {"wf_maph", &Options::wf_maph, nullptr, 0, 1},
+    {"gemm_stream", &Options::gemm_stream, nullptr, 0, 1}, {"sk_minunits", &Options::sk_minunits, nullptr, 1, 1 << 20},
+    {"combine_v", &Options::combine_v, nullptr, 0, 1}, {"wf_mixed", &Options::wf_mixed, nullptr, 0, 1},
+    {"channel_rows", &Options::channel_rows, nullptr, 0, 4},
     {"wf_trace", &Options::wf_trace, nullptr, 0, 1}, {"igemm_trace", &Options::igemm_trace, nullptr, 0, 1},
 };
 const OptEntry* find_option(const char* name) {
@@ -1451,11 +1449,6 @@ int ffr_set_option(ffr_handle* h, const char* name, long long value) {
     if ((e->i == &Options::wf_trace || e->i == &Options::igemm_trace) && value)
         return fail(h, FFR_ERR_UNSUPPORTED, "ffr_set_option: %s needs a -DFFR_TRACE build of the library (tools/trace_build.py)", name);
 #endif
-    if (e->i == &Options::wino_112 && h->opt.wino_112 != (int)value && h->arena) {
-        // the workspace layout depends on it: drop the arena, the next call lays it out again
-        FFR_DEVICE_SCOPE(h);
-        hipDeviceSynchronize(); hipFree(h->arena); h->arena = nullptr; h->arena_bytes = 0; ++h->generation;
-    }
     // every knob changes which kernels a forward launches or which scratch buffers they use: a hipGraph captured
     // before the change replays the OLD sequence, so a changed value invalidates captures (GraphedEmbed re-captures
     // when ffr_generation moves)
@@ -1571,7 +1564,7 @@ int ffr_op_conv3x3(ffr_handle* h, const float* x, int N, int H, int W, int cin, 
     if (rc == FFR_OK && use_wino && !L.wu) rc = fail(h, FFR_ERR_UNSUPPORTED, "layer not eligible for the Winograd path (cin < FFR_WINO_MINCIN)");
     if (rc == FFR_OK && use_wino == 4) {
         if (!wino_mixed_eligible(h, L, N, H, W, cin, w.wino_cap, 4)) rc = fail(h, FFR_ERR_UNSUPPORTED, "layer / map not eligible for the mixed-tile path");
-        else rc = ensure_mixed_weights(h, L, own);
+        else rc = ensure_mixed_weights(h, L, own, true);
     }
     if (rc == FFR_OK) {
         ConvCall c{};
@@ -1595,7 +1588,7 @@ int ffr_encoder_trunk_nhwc(ffr_handle* h, const float* x, int N, int H, int W, i
     if (H < 32 || W < 32 || (H & 15) || (W & 15)) return fail(h, FFR_ERR_ARG, "H and W must be multiples of 16, >= 32");
     hipStream_t st = (hipStream_t)stream;
     Work w;
-    RC(ensure_arena(h, N, H, W, &w));
+    RC(ensure_arena_encoder(h, N, H, W, &w));
     float* t; int oh, ow, oc;
     RC(run_trunk(h, w, x, N, H, W, n_blocks, st, &t, &oh, &ow, &oc));
     HIPCK(h, hipMemcpyAsync(out, t, (size_t)N * oh * ow * oc * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -34,6 +34,7 @@ struct ConvW {
     float* wum[4] = {nullptr, nullptr, nullptr, nullptr};   // mixed tile sizes (wino_mixed.hip): weights of the tile types (4,3), (3,4), (3,3) in fragment
                              // order at [1..3] ([0] = wuc); derived on the device from `w` the first time a launch of this layer is eligible
                              // (engine.cpp, ensure_mixed_weights), null before
+    bool wum_gave_up = false;   // the device could not hold this layer's extra sets: it stays on padded F(4x4) tiles (never retried)
     float* wuc = nullptr;    // the same in the K-chunk order k_wino_fused streams ([cout_pad/64][cin_pad/8][36][128][4]) or null
 };
 
@@ -50,28 +51,19 @@ struct Block {
 struct Options {
     int wino = 1;                 // 0: every 3x3 convolution of the inference path runs as a direct implicit GEMM
     int wino_mincin = 64;         // smallest padded input-channel count packed for Winograd (takes effect at load time)
-    int wino_112 = 1;             // 0: no Winograd workspace for the 112x112 layer (it then runs direct)
     int wino_fused = 1;           // 0: Winograd convolutions run as transform kernels around the batched GEMM
     int wf_phased_maxk = 128;     // largest padded cin for which k_wino_fused transforms its own input
     long long wf_minblocks = 200; // fewest block tiles for which the fused kernel is used
-    int wf_halfblocks = 1;        // 1: launches below wf_minblocks use the 32-tile x 32-channel block shape (NT = 1) when that fills the chip
-    int se_maxtiles = 256;        // most 4x4 tiles per image for which the SE squeeze comes from the fused kernel's tile sums
+    int se_maxtiles = 256;        // most 4x4 tiles per image for which the SE squeeze comes from the fused kernel's tile sums (0: own pass)
     int wf_tailsplit = 1;         // 1: images that do not fill whole rounds of block tiles run on the second stream
-    int wf_mapv = 1;              // block -> tile map of k_wino_fused (1: channel groups of a tile group share an XCD)
-    long long wino_slice_mb = 0;  // > 0: round-1 Winograd path in sub-batches of this many MiB
     int gemm_stream = 1;          // 0: the 36 Winograd GEMMs go through k_igemm (batched) instead of k_gemm_stream
-    int gs_tile = 0;              // 1 / 2: force the 128x128 / 128x64 tile of k_gemm_stream
     int sk_minunits = 18;         // smallest number of K-tiles a stream-K block may own
-    int wino_oi = 1;              // (wino_fused = 0 only) conv1 output transform + conv2 input transform in one kernel
-    int se_fuse = 1;              // 0: the SE squeeze always pools res in its own pass
     int wf_mixed = 1;             // 1: 14x14 maps are tiled 4+4+3+3 (k_wino_fused_mixed) when the launch gives every CU two blocks or more
-    int wf_maph = 0;              // (measured round 5: <0,2> fetches 5.23 -> 4.25 GB per step, the forward 15.25 vs 15.19 ms: off) V-fed k_wino_fused with >= 4 channel groups: the two XCD quads split the channel groups (half of U per L2, V read twice)
-    int wf_mapx = 1;              // k_wino_fused with the in-kernel input transform: an XCD owns a contiguous range of tile groups (halo rows shared in its L2)
-    int wm_xcdpairs = 1;          // k_wino_fused_mixed: XCDs specialise in pairs of tile types (round 5)
     int channel_rows = 0;         // k_channel_path: blocks per image (1, 2, 4); 0 = from the batch and the CU count (round 5)
-    int igemm_tile64 = 0;         // > 0: tile shape forced for large direct convolutions with 64 output channels (1..4, ffr_conv_desc.tile)
     int combine_v = 1;            // 1: a bottleneck's combine also writes V for the next conv1 when that runs k_wino_fused from V
     int wf_trace = 0, igemm_trace = 0;   // -DFFR_TRACE builds only: per-launch phase stamps on stderr (synchronises)
+    // Retired in round 6, their A/B settled (EXPERIMENTS.md): wino_112, wf_halfblocks, wf_mapv, wf_mapx, wf_maph, wm_xcdpairs,
+    // wino_slice_mb, gs_tile, wino_oi, se_fuse, igemm_tile64 -- the code keeps the measured-best setting of each.
 };
 
 struct ProfRec {
@@ -96,7 +88,9 @@ struct ffr_handle {
     size_t enc_weight_bytes = 0, rec_weight_bytes = 0;      // device bytes of the packed weights (ffr_memory_stats)
     size_t mixed_weight_bytes = 0;                          // of them: the lazily derived weight sets of the exact 14x14 tiling
     double enc_load_s = 0.0, rec_load_s = 0.0, mixed_pack_s = 0.0;   // wall seconds of the last ffr_load_* / of all lazy packs
-    int mixed_ready_n = 0, mixed_ready_h = 0, mixed_ready_w = 0;     // prepare_mixed_weights ran for batches up to n of h x w
+    bool mixed_gave_up_logged = false;
+    int mixed_ready_n = 0, mixed_ready_h = 0, mixed_ready_w = 0;     // prepare_mixed_weights ran for batches up to n of h x w (a shortcut only:
+                                                                     // readiness itself is per layer, ConvW::wum / wum_gave_up)
     float *stem_w = nullptr, *stem_b = nullptr, *stem_s = nullptr;
     std::vector<ffr_eng::Block> blocks;      // 24 / 49 / 50 bottlenecks: Backbone(50 | 100 | 152), with or without SE
     float *bn_s = nullptr, *bn_t = nullptr;
@@ -222,7 +216,7 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
 bool wino_accepts_ready_v(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap);
 bool wino_mixed_applies(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode);
 bool wino_mixed_eligible(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode);
-int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner);
+int ensure_mixed_weights(ffr_handle* h, ConvW& L, std::vector<void*>& owner, bool strict);
 int prepare_mixed_weights(ffr_handle* h, int N, int H, int W, size_t wino_cap);
 int run_gemm(ffr_handle* h, IgemmArgs& a, const ConvCall& c, double flops, double bytes, hipStream_t st, double fuse = -1.0);
 int run_conv(ffr_handle* h, const ConvW& L, const ConvCall& c, hipStream_t st);
@@ -252,6 +246,7 @@ struct Work {
 
 Work layout(const Options& opt, char* base, int N, int H, int W);
 int ensure_arena(ffr_handle* h, int N, int H, int W, Work* w);
+int ensure_arena_encoder(ffr_handle* h, int N, int H, int W, Work* w);     // + the exact-tiling weight sets an encoder forward of this size uses
 struct U8In { const unsigned char* img; const unsigned char* flip; };
 int run_encoder(ffr_handle* h, const Work& w, const float* x, int N, int H, int W, float* featmap_nhwc, float* f,
                 hipStream_t st, const U8In* u8 = nullptr, const float* x2 = nullptr, int n_split = 0);

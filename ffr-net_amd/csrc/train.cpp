@@ -974,6 +974,24 @@ int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_
     Ctx& c = t->ctx[slot];
     if (!c.mem) return fail(h, FFR_ERR_STATE, "no forward in slot %d", slot);
     const std::string k = name;
+    // "y.sp3" / "scale.fm0" / "shift.mg2": raw convolution output [rows][cout_pad] and the batch-norm scale / shift [G][cout_pad] of
+    // ConvLayer i of Conv4Space (sp 0..8), ChannelFlipMerge (fm 0..2), Conv4Merge (mg 0..2): the PReLU pre-activation is
+    // y * scale + shift -- the tests read its SIGN pattern (which side of the kink every element fell on)
+    {
+        const size_t dot = k.find('.');
+        if (dot != std::string::npos && k.size() == dot + 4) {
+            const std::string what = k.substr(0, dot), set = k.substr(dot + 1, 2);
+            const int i = k[dot + 3] - '0';
+            const TSaved* sv = set == "sp" && i >= 0 && i < 9 ? &c.sp[i] : set == "fm" && i >= 0 && i < 3 ? &c.fm[i] :
+                               set == "mg" && i >= 0 && i < 3 ? &c.mg[i] : nullptr;
+            const float* p = !sv ? nullptr : what == "y" ? sv->y : what == "scale" ? sv->bn.scale : what == "shift" ? sv->bn.shift : nullptr;
+            if (p) {
+                HIPCK(h, hipDeviceSynchronize());
+                HIPCK(h, hipMemcpy(host_out, p, n * 4, hipMemcpyDeviceToHost));
+                return FFR_OK;
+            }
+        }
+    }
     const float* src = k == "cat" ? c.cat : k == "h1pre" ? c.h1pre : k == "h1" ? c.h1 : k == "t2" ? c.t2 : k == "h2pre" ? c.h2pre :
                        k == "h3pre" ? c.h3pre : k == "Mc" ? c.Mc : k == "raw" ? c.raw : k == "X" ? c.X : k == "Xht" ? c.Xht :
                        k == "d32a" ? t->d32a : k == "d32b" ? t->d32b : k == "dMc" ? t->dMc : k == "dt" ? t->dt :
@@ -1098,7 +1116,7 @@ int ffr_train_iteration(ffr_handle* h, const float* img_non, const float* img_oc
     hipStream_t st = (hipStream_t)stream;
     const int imgs = 2 * N;
     Work w;
-    RC(ensure_arena(h, imgs, 112, 112, &w));
+    RC(ensure_arena_encoder(h, imgs, 112, 112, &w));        // the frozen encoder runs on both image sets
     RC(ensure_scratch(h, t, imgs));
     Ctx& c = t->ctx[0];
     RC(ensure_ctx(h, t, c, 2, N));

@@ -433,10 +433,7 @@ __global__ __launch_bounds__(256, 1) void k_wino_fused(const WinoFusedArgs a) {
     // The first NPRE patch values of a phase (its first columns) are requested under the LAST K chunk of the phase before
     // (its weight-fragment slots are dying there), so the memory latency of a phase's first access (~2.5k cycles from HBM)
     // is paid under MFMAs and the column passes start at once.
-#ifndef FFR_WF_NPRE
-#define FFR_WF_NPRE 16          // tools/npre_experiment.py builds 24 / 32 for comparison (round 5: see DESIGN.md 3.2)
-#endif
-    constexpr int NPRE = FFR_WF_NPRE;
+    constexpr int NPRE = 16;        // 24 / 32 measured in round 5: no gain, more spills (EXPERIMENTS.md)
     f32x4 pre[NPRE];
     auto load_px = [&](int idx, unsigned so) {          // patch value idx = j * 6 + i (column-major)
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ro[idx % 6] + co[idx / 6], so, 0));

@@ -168,34 +168,28 @@ int ffr_profile_enable(ffr_handle* h, int on);
  * results (tests/test_gpu_parity.py::test_experiment_knobs_keep_parity).  Defaults = the measured best.
  *   "wino" (1)            0: every 3x3 convolution of the inference path is a direct implicit GEMM
  *   "wino_mincin" (64)    smallest padded input-channel count packed for Winograd; set BEFORE ffr_load_*
- *   "wino_112" (1)        0: no Winograd workspace for the 112x112 layer (it runs direct; smaller arena)
  *   "wino_fused" (1)      0: Winograd convolutions run as transform kernels around a batched GEMM (round-1 path)
  *   "wf_phased_maxk" (128) largest padded cin for which k_wino_fused transforms its own input
  *   "wf_minblocks" (200)  fewest 32-tile x 64-channel block tiles for which k_wino_fused is used
- *   "wf_halfblocks" (1)   1: below that limit the 32-tile x 32-channel block shape (NT = 1) is used when it fills the chip
  *   "wf_tailsplit" (1)    1: images that do not fill whole rounds of block tiles run beside the launch (second stream)
- *   "wf_mapv" (1)         block -> tile map of k_wino_fused: 1 = the channel groups of a tile group share an XCD
- *   "se_maxtiles" (256), "se_fuse" (1)   SE squeeze from the Winograd epilogue's tile sums (up to that many tiles / at all)
+ *   "se_maxtiles" (256)   SE squeeze from the Winograd epilogue's tile sums for maps of up to that many tiles (0: always its own pass)
  *   "wf_mixed" (1)        1: 14x14 maps (stage 3) are tiled exactly, 4+4+3+3 per dimension, with four tile types F(4x4) / F(4x3) /
  *                         F(3x4) / F(3x3) in one launch (k_wino_fused_mixed) whenever every CU gets two blocks or more; 0: padded
  *                         F(4x4) tiles only.  May be changed at any time: the three extra weight sets are derived on the device the
- *                         first time a launch is eligible (ffr_memory_stats reports their bytes and seconds)
- *   "igemm_tile64" (0)    1..4: tile shape forced for the large direct convolutions with 64 output channels (ignored where the
- *                         tile's width does not divide the padded channel count)
- *   "wm_xcdpairs" (1)     k_wino_fused_mixed: XCDs 0-3 run the tile types (4,4) + (3,3), XCDs 4-7 (4,3) + (3,4): two weight sets per L2 and
- *                         launch instead of four (12.7 -> 9.2 GB fetched per forward, -0.6 % time); 0: every XCD runs all four types
- *   "wf_mapx" (1)         k_wino_fused with the in-kernel input transform: an XCD owns a contiguous range of tile groups, so the
- *                         halo rows neighbouring tile rows share are fetched into one L2 (7.7 -> 6.6 GB per forward); 0: round-robin
- *   "wf_maph" (0)         V-fed k_wino_fused with >= 4 channel groups: the two XCD quads split the channel groups (half of U per L2, V
- *                         read twice: 5.2 -> 4.2 GB per forward, but 15.25 vs 15.19 ms: off)
+ *                         first time an ENCODER call (ffr_reserve, ffr_encoder_forward, ffr_embed*, the training iteration) is
+ *                         eligible (ffr_memory_stats reports their bytes and seconds).  They are an optimisation: a device that
+ *                         cannot hold them (0.7 GB) keeps the layers concerned on padded tiles, logs once and does not fail.
+ *                         To capture ffr_embed into a hipGraph call ffr_reserve(N, H, W) (or run one eager forward) first.
  *   "channel_rows" (0)    k_channel_path (RecNet's channel branch): 1 / 2 / 4 blocks per image (128 CT rows of M_channel each);
  *                         0 = chosen from the batch and the CU count (fewer images than CUs -> more blocks per image)
  *   "combine_v" (1)       1: a bottleneck's combine (res * scale + shortcut) also writes the Winograd transform V of its
  *                         output when the next unit's conv1 runs k_wino_fused from V (stage 3 / 4): k_combine_in_c
  *                         replaces k_combine + k_wino_in_c
- *   "gemm_stream" (1), "gs_tile" (0), "sk_minunits" (18), "wino_oi" (1), "wino_slice_mb" (0)   round-1 path details
+ *   "gemm_stream" (1), "sk_minunits" (18)   round-1 path details (batched-GEMM Winograd, stream-K granule)
  *   "wf_trace", "igemm_trace" (0)   per-launch phase stamps on stderr; only in a -DFFR_TRACE build (tools/trace_build.py),
  *                                    the shipped library returns FFR_ERR_UNSUPPORTED
+ * (Round 6 retired the knobs whose A/B is settled -- block -> XCD maps, half blocks, forced tiles, round-1 slicing; the code
+ * keeps the measured-best setting of each, EXPERIMENTS.md has the numbers.)
  * Unknown names and out-of-range values return FFR_ERR_ARG.                                                        */
 int ffr_set_option(ffr_handle* h, const char* name, long long value);
 int ffr_get_option(const ffr_handle* h, const char* name, long long* value);

@@ -125,7 +125,10 @@ int ffr_train_option(ffr_handle* h, const char* name, int value);
 
 /* Test hook: the first n floats of a named intermediate buffer of context `slot` (forward activations:
  * "X" "cat" "h1pre" "h1" "t2" "h2pre" "h3pre" "Mc" "raw" "Xht"; backward scratch: "d32a" "d32b" "dMc" "dt"
- * "dBufM" "dF" "dms"; loss gradients: "df_ext" "dcos" "extM") copied to host memory, in the kernel layouts.  Synchronises the device.          */
+ * "dBufM" "dF" "dms"; loss gradients: "df_ext" "dcos" "extM"; per ConvLayer i of Conv4Space / ChannelFlipMerge / Conv4Merge
+ * ("sp0".."sp8", "fm0".."fm2", "mg0".."mg2"): "y.<layer>" the raw convolution output [G*N*49][cout_pad], "scale.<layer>" /
+ * "shift.<layer>" the batch-norm scale and shift [G][cout_pad] -- the PReLU pre-activation is y * scale + shift)
+ * copied to host memory, in the kernel layouts.  Synchronises the device.                                       */
 int ffr_train_debug_copy(ffr_handle* h, int slot, const char* name, float* host_out, size_t n);
 
 #ifdef __cplusplus

@@ -68,6 +68,72 @@ def test_convlayer_train_forward_backward(engine, case):
     assert rel(res['dslope'], sr.grad) < GRAD_TOL
 
 
+# ---- PReLU kinks ------------------------------------------------------------------------------------------
+# RecNet has 2.1 M PReLU inputs in an 8-image step; a forward that differs from the reference's by 1e-5 (F(4x4,3x3) in fp32,
+# another encoder) puts a few dozen of them on the other side of zero, and each such element changes its own gradient by
+# (1 - slope) -- percents of a parameter gradient's norm, although NOTHING is wrong (the oracle does the same to itself:
+# a 1e-5 relative perturbation of its float64 inputs moves its own gradients by 7e-3..1e-2 in relative L2, a 1e-6 one by
+# 3e-6; tools/train_grad_report.py).  The reference-pinned check of a gradient therefore takes the SIGN PATTERN the GPU
+# forward produced (ffr_train_debug_copy: y * scale + shift per ConvLayer, the three row pre-activations of
+# Conv4Channel), evaluates the oracle's gradient formula on THAT side of every kink (ffr_oracle_train._prelu, ctl['mask']),
+# and (a) holds the GPU gradients to it tightly, per tensor, in the default (Winograd) arithmetic and with the real slopes;
+# (b) requires every element whose side differs from the oracle's own to lie within the forward tolerance of zero -- the
+# only place where two correct fp32 forwards may disagree.
+def gpu_kink_masks(eng, groups, n, slot=0):
+    """{oracle PReLU name: [groups * n, ...] bool, True = the identity side} of the forward held in `slot`."""
+    import ffr_oracle_train as OT
+    imgs = groups * n
+    masks = {}
+    for name, dbg in OT.PRELU_LAYERS:
+        if dbg.startswith('h'):
+            masks[name] = eng.train_debug(dbg, (imgs * 512, 64), slot)[:, :32].reshape(imgs, 512, 32) > 0
+            continue
+        c = {'sp': (256, 256, 256, 128, 128, 128, 49, 49, 49), 'fm': (512,) * 3, 'mg': (512,) * 3}[dbg[:2]][int(dbg[2])]
+        cp = (c + 63) // 64 * 64
+        y = eng.train_debug('y.' + dbg, (groups, n * 49, cp), slot).double()
+        sc = eng.train_debug('scale.' + dbg, (groups, 1, cp), slot).double()
+        sh = eng.train_debug('shift.' + dbg, (groups, 1, cp), slot).double()
+        z = (y * sc + sh).reshape(imgs, 7, 7, cp)[..., :c].permute(0, 3, 1, 2)      # the kernel's fma, exactly (float64 holds the product)
+        masks[name] = z > 0
+    return masks
+
+
+def oracle_grads_on_masks(sd_r, fm, f_enc, label, masks, n):
+    """The oracle's parameter gradients of Trainer.backward's loss with every PReLU element on the side `masks` says
+    (None: its own side).  fm / f_enc: [2 n, ...] clean then occluded.  -> ({key: grad}, natural pre-activations, items)"""
+    import ffr_oracle_train as OT
+    keys = OT.trainable_keys(sd_r)
+    params = {k: sd_r[k].clone().requires_grad_(True) for k in keys}
+    running = {k: v.clone() for k, v in sd_r.items() if k not in params}
+    ctl = [{'mask': {k: m[:n] for k, m in masks.items()}} if masks else {}, {'mask': {k: m[n:] for k, m in masks.items()}} if masks else {}]
+    out_non = OT.recnet_train_forward(params, fm[:n], label, running, ctl[0])
+    out_ocl = OT.recnet_train_forward(params, fm[n:], label, running, ctl[1])
+    items = OT.trainer_losses(out_non, out_ocl, fm[:n], f_enc[:n], f_enc[n:], label)
+    grads = torch.autograd.grad(sum(items), [params[k] for k in keys], allow_unused=True)
+    pre = {k: torch.cat([ctl[0]['pre'][k], ctl[1]['pre'][k]]) for k in ctl[0]['pre']}
+    return {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(keys, grads)}, pre, [float(i.detach()) for i in items]
+
+
+def check_kinks(masks, pre, tol):
+    """Every element whose side differs from the oracle's own lies within `tol` (relative to its layer's largest
+    pre-activation) of zero.  -> number of such elements."""
+    flipped = 0
+    for k, m in masks.items():
+        nat = pre[k]
+        diff = m != (nat > 0)
+        if diff.any():
+            margin = (nat[diff].abs().max() / nat.abs().max()).item()
+            assert margin < tol, (k, int(diff.sum()), margin)
+            flipped += int(diff.sum())
+    return flipped
+
+
+def grad_err(got, ref):
+    # a BatchNorm bias in front of [identity -> conv -> BatchNorm] has a gradient that is zero up to rounding
+    # (the next BatchNorm removes the shift): errors are taken relative to at least 1e-3
+    return ((got.double().cpu() - ref.double()).abs().max() / max(ref.abs().max().item(), 1e-3)).item()
+
+
 # ---- the whole RecNet training step ---------------------------------------------------------------
 @pytest.fixture(scope='module')
 def train_case(specs):
@@ -136,14 +202,12 @@ def test_train_forward_matches_oracle_and_golden(engine, train_case, golden_dir)
 
 
 def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir):
-    """loss.backward() through RecNet (models/trainer.py:179-180): parameter gradients for the reference's
-    four losses, cotangents of the 7-tuple taken from the oracle's autograd."""
+    """loss.backward() through RecNet (models/trainer.py:179-180): the 76 parameter gradients for the reference's four
+    losses (cotangents of the 7-tuple from the oracle's autograd), in BOTH arithmetics -- direct convolutions and the
+    DEFAULT (Winograd F(4x4,3x3) forward and data-gradient convolutions) -- with the reference's real PReLU slopes,
+    per tensor, against (1) the oracle on the GPU's side of every kink (see "PReLU kinks" above) and (2) golden G8, the
+    clipped gradients of the reference's own Trainer, plus exactly the difference the transplanted kinks make."""
     tc = train_case
-    engine.train_init(tc['sd_r'])
-    # direct convolutions here: on this 8-image batch a 1e-6 change of rounding (Winograd, a different encoder)
-    # moves pre-activations across PReLU kinks and some cancelling sums by percents; see the next test
-    engine.train_option('winograd', 0)
-    engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
     og = tc['out_grads']
     stacked = []
     for i in range(7):
@@ -155,43 +219,43 @@ def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir
         a = a if a is not None else torch.zeros(ref_shape)
         b = b if b is not None else torch.zeros(ref_shape)
         stacked.append(torch.cat([a, b]).cuda())
-    engine.train_zero_grad()
-    engine.train_backward(stacked)
-    torch.cuda.synchronize()
     g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
-    worst = ('', 0.0)
-    # One pre-activation of the first Conv4Channel PReLU is 2.2e-8 in this scenario (|h1pre| max 5.8): the
-    # GPU and the CPU round it to opposite sides of the PReLU kink, which moves that element's gradient by
-    # 1 - slope (tools/train_grad_report.py prints the flip).  Only the first linear sees it undiluted.
-    kink = {'Conv4Channel.0.weight': 5e-3, 'Conv4Channel.0.bias': 5e-3}
+    natural, pre, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], None, 4)
     for k in tc['keys']:
-        got = engine.train_get(k, 'grad')
-        ref = tc['param_grads'][k]
-        e = rel(got, ref) if ref.abs().max() > 0 else got.abs().max().item()
-        if e > worst[1]:
-            worst = (k, e)
-        assert e < kink.get(k, 1e-4), (k, e)
-        # the reference's own (clipped) gradients: digest = [sum, abs-sum, 64 strided samples]
-        d = g8['grad.' + k]
-        c = got.clamp(-1.0, 1.0)
-        f = c.reshape(-1)
-        samples = f[::max(1, f.numel() // 64)][:64].double()
-        assert rel(samples, torch.from_numpy(d[2:])) < kink.get(k, 1e-4), k
-        assert abs(c.double().abs().sum().item() - d[1]) <= kink.get(k, 1e-4) * max(d[1], 1e-12), k
-    print('worst gradient error', worst)
-    # the default path (Winograd F(4x4,3x3) forward and data-gradient convolutions): same gradients in relative L2
-    engine.train_init(tc['sd_r'])
-    engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
-    engine.train_zero_grad()
-    engine.train_backward(stacked)
-    torch.cuda.synchronize()
-    for k in tc['keys']:
-        got = engine.train_get(k, 'grad')
-        ref = tc['param_grads'][k]
-        l2 = ((got - ref).norm() / ref.norm().clamp_min(1e-30)).item()
-        # sanity bound only: on this kinked 8-image batch the figure moves between 5e-3 and 2.3e-2 from run to run with
-        # the last bits of the CPU-computed inputs; the tight check of the Winograd mode is the kink-free test below
-        assert l2 < 1e-1, (k, l2)
+        assert grad_err(natural[k], tc['param_grads'][k]) < 1e-6     # the helper IS build_train_case's computation
+    for mode, tol, fwd_tol in ((0, 1e-4, 1e-5), (1, 3e-4, 1e-4)):
+        engine.train_init(tc['sd_r'])
+        engine.train_option('winograd', mode)
+        engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
+        masks = gpu_kink_masks(engine, 2, 4)
+        flipped = check_kinks(masks, pre, fwd_tol)
+        engine.train_zero_grad()
+        engine.train_backward(stacked)
+        torch.cuda.synchronize()
+        ref, _, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], masks, 4)
+        worst = ('', 0.0)
+        moved = 0.0
+        for k in tc['keys']:
+            got = engine.train_get(k, 'grad')
+            e = grad_err(got, ref[k])
+            worst = max(worst, (k, e), key=lambda t: t[1])
+            assert e < tol, (mode, k, e)
+            moved = max(moved, grad_err(ref[k], natural[k]))
+            # the reference's own (clipped) gradients: digest = [sum, abs-sum, 64 strided samples] + what the kinks moved
+            d = g8['grad.' + k]
+
+            def samples(t):
+                f = t.clamp(-1.0, 1.0).reshape(-1)
+                return f[::max(1, f.numel() // 64)][:64].double().cpu()
+            expect = torch.from_numpy(d[2:]) + samples(ref[k]) - samples(natural[k])
+            scale = max(np.abs(d[2:]).max(), 1e-3)
+            assert (samples(got) - expect).abs().max().item() / scale < tol, (mode, k)
+            asum = d[1] + ref[k].clamp(-1, 1).double().abs().sum().item() - natural[k].clamp(-1, 1).double().abs().sum().item()
+            assert abs(got.clamp(-1.0, 1.0).double().abs().sum().item() - asum) <= tol * max(d[1], 1e-3 * got.numel()), (mode, k)
+        print('winograd=%d: %d of 2.1 M PReLU inputs on the other side of zero (all within %.0e of it); they move the '
+              'oracle\'s own gradients by up to %.2e; worst GPU gradient error on the same side %.2e (%s)'
+              % (mode, flipped, fwd_tol, moved, worst[1], worst[0]))
+    engine.train_option('winograd', 1)
 
 
 def test_adam_and_clip_match_torch(engine, specs):
@@ -243,42 +307,45 @@ def test_native_trainer_step_matches_reference(specs, golden_dir):
     for k in sd_after:
         if k.endswith(('running_mean', 'running_var')):
             assert rel(sd_after[k], torch.from_numpy(g8['after.' + k]).float()) < 1e-4, k
-    # The parameter gradients of this 8-image batch move by percents when the feature map moves by 1e-5 (the GPU
-    # encoder's rounding): pre-activations cross PReLU kinks and the per-channel sums over 392 rows cancel
-    # heavily.  So the gradients are held to the oracle evaluated ON THE GPU's feature maps (same inputs, the
-    # remaining differences are rounding only), in relative L2 per tensor.
-    import ffr_oracle as O
+    # The feature maps here are the GPU encoder's (1e-5 from the CPU's), so the gradients are held to the oracle evaluated
+    # ON those feature maps and on the GPU's side of every PReLU kink ("PReLU kinks" above): per tensor, tight, real slopes.
+    import ffr_oracle as O  # noqa: F401
     fm, f_enc = eng.encoder_forward(torch.cat((non, ocl)).cuda())
     fm, f_enc = fm.cpu(), f_enc.cpu()
     keys = OT.trainable_keys(sd_r)
-    params = {k: sd_r[k].clone().requires_grad_(True) for k in keys}
-    running = {k: v.clone() for k, v in sd_r.items() if k not in params}
-    out_non = OT.recnet_train_forward(params, fm[:4], label, running)
-    out_ocl = OT.recnet_train_forward(params, fm[4:], label, running)
-    ref_items = OT.trainer_losses(out_non, out_ocl, fm[:4], f_enc[:4], f_enc[4:], label)
-    ref_grads = torch.autograd.grad(sum(ref_items), [params[k] for k in keys])
-    for k, rg in zip(keys, ref_grads):
-        got_g = eng.train_get(k, 'grad')
-        l2 = ((got_g - rg).norm() / rg.norm().clamp_min(1e-30)).item()
-        assert l2 < 5e-3, (k, l2)
+    _, pre, _ = oracle_grads_on_masks(sd_r, fm, f_enc, label, None, 4)
+
+    def check_iteration(tol, fwd_tol, tag):
+        masks = gpu_kink_masks(eng, 2, 4)
+        flipped = check_kinks(masks, pre, fwd_tol)
+        ref, _, ref_items = oracle_grads_on_masks(sd_r, fm, f_enc, label, masks, 4)
+        worst = 0.0
+        for k in keys:
+            got_g = eng.train_get(k, 'grad')
+            e = grad_err(got_g, ref[k])
+            worst = max(worst, e)
+            assert e < tol, (tag, k, e)
+        print('%s: %d kinks transplanted, worst gradient error %.2e' % (tag, flipped, worst))
+        return ref
+
+    check_iteration(1e-4, 1e-5, 'whole iteration, direct')
+    for k in keys:
         # the optimiser inside the step: Adam's first update of the clipped native gradient, torch's formula
-        gc = got_g.clamp(-1.0, 1.0)
+        gc = eng.train_get(k, 'grad').clamp(-1.0, 1.0)
         m, v = 0.1 * gc, 0.001 * gc * gc
         expect = sd_r[k] - (0.1 / 0.1) * m / ((v.sqrt() / (1.0 - 0.999) ** 0.5) + 1e-8)
         assert (sd_after[k] - expect).abs().max().item() < 2e-5, k
-    # default mode (Winograd forward / data-gradient convolutions): same losses, gradients within the kink noise
-    direct = {k: eng.train_get(k, 'grad') for k in keys}
+    # DEFAULT mode (Winograd forward / data-gradient convolutions): same losses, gradients per tensor as tight as above
     tr2 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
     items2 = tr2.step(non.cuda(), ocl.cuda(), label.cuda())
     assert np.allclose(np.array([float(l) for l in items2]), g8['losses'], rtol=1e-4)
+    check_iteration(3e-4, 1e-4, 'whole iteration, default (Winograd)')
     # the same iteration with the loss items evaluated by torch ops instead of the native loss kernels
     tr3 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
     items3 = TL.step_torch_losses(tr3, non.cuda(), ocl.cuda(), label.cuda())
     assert np.allclose(np.array([float(l) for l in items3]), np.array([float(l) for l in items2]), rtol=1e-4)
     assert float(tr3.accuracy) == float(tr2.accuracy)
-    for k in keys:
-        l2 = ((eng.train_get(k, 'grad') - direct[k]).norm() / direct[k].norm().clamp_min(1e-30)).item()
-        assert l2 < 1e-1, (k, l2)      # kink noise, see test_train_backward_kink_free_network_both_modes
+    check_iteration(3e-4, 1e-4, 'whole iteration, default, torch loss items')
 
 
 def test_train_backward_kink_free_network_both_modes(engine, specs):
@@ -393,10 +460,11 @@ def test_native_loss_items_and_their_gradients(engine, train_case):
     engine.train_zero_grad()
     engine.train_backward_losses()
     torch.cuda.synchronize()
-    kink = {'Conv4Channel.0.weight': 5e-3, 'Conv4Channel.0.bias': 5e-3}
+    masks = gpu_kink_masks(engine, 2, 4)
+    ref, _, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], masks, 4)
     for k in tc['keys']:
-        ref = tc['param_grads'][k]
-        assert rel(engine.train_get(k, 'grad'), ref) < kink.get(k, 2e-4), k
+        assert grad_err(engine.train_get(k, 'grad'), ref[k]) < 2e-4, k
+    engine.train_option('winograd', 1)
 
 
 def test_training_full_size_properties(specs):
