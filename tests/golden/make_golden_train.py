@@ -7,7 +7,7 @@ What runs is the reference's RecNet (train mode), AddMarginProduct head, Trainer
 Trainer.backward, clip_grad_value_ and torch.optim.Adam (models/trainer.py:139-187) on 4 seeded
 synthetic pairs with the synthetic weights of ffr-net_amd/synth.py.  Stored: the 7-tuple outputs,
 the four loss items, per-parameter gradient digests (sum, abs-sum, 64 strided samples), BN running
-statistics and parameter samples after one step.  Only outputs are stored, no reference source.
+statistics and parameter samples after one step, and the side of its kink every near-zero PReLU input fell on.  Only outputs are stored, no reference source.
 
 Two accommodations, both outside the reference's files: the Trainer is built with object.__new__
 (its __init__ loads ./pretrain/se50.pth, which does not exist), and torch.zeros ignores the
@@ -70,6 +70,25 @@ def main():
 
     non, ocl, label = synth.synth_train_batch(B, seed=SEED)
     t.set_input(non, ocl, label)
+    # Which side of its PReLU kink every NEAR-ZERO pre-activation fell on in this run of the reference (|x| < 1e-4 of the
+    # layer's largest; ~170 of 2.1 M elements): another host's rounding can put the few elements within 1e-6 of zero on the
+    # other side, which changes their gradients by (1 - slope).  With the recorded sides the oracle reproduces THIS run's
+    # gradients on any host (tests/test_gpu_train.py, "PReLU kinks").
+    kinks = {}
+    calls = {}
+
+    def pre_hook(name):
+        def fn(mod, inp):
+            tag = ('non', 'ocl')[calls.get(name, 0)]
+            calls[name] = calls.get(name, 0) + 1
+            x = inp[0].detach()
+            near = (x.abs() < 1e-4 * x.abs().max()).reshape(-1).nonzero().reshape(-1)
+            kinks['kink.%s.%s.idx' % (name, tag)] = near.numpy().astype(np.int64)
+            kinks['kink.%s.%s.side' % (name, tag)] = (x.reshape(-1)[near] > 0).numpy()
+            kinks['kink.%s.%s.absmax' % (name, tag)] = np.float64(x.abs().max().item())
+        return fn
+    hooks = [m.register_forward_pre_hook(pre_hook(n[:-len('.relu')] if n.endswith('.relu') else n))
+             for n, m in rec.named_modules() if type(m).__name__ == 'ReluLayer']
     zeros = torch.zeros
     torch.zeros = lambda *a, **k: zeros(*a, **{kk: vv for kk, vv in k.items() if kk != 'device'})
     before = {k: v.detach().clone() for k, v in rec.state_dict().items()}
@@ -82,7 +101,10 @@ def main():
         t.optimizer_parameters(1)
     finally:
         torch.zeros = zeros
-    g8 = dict(B=np.int64(B), lr=np.float64(LR), label=label.numpy(),
+    for hk in hooks:
+        hk.remove()
+    assert len(kinks) == 3 * 2 * 18, len(kinks)
+    g8 = dict(B=np.int64(B), lr=np.float64(LR), label=label.numpy(), **kinks,
               input_checksum=np.float64(non.double().sum().item() + ocl.double().sum().item()),
               losses=np.array([float(l.detach()) for l in t.loss_items], dtype=np.float64),
               accuracy=np.float64(t.accuracy))
@@ -104,6 +126,7 @@ def main():
             assert int(after[k]) == int(before[k]) + 2
     np.savez_compressed(os.path.join(HERE, 'g8_train_step.npz'), **g8)
     print('losses', g8['losses'], 'acc', g8['accuracy'])
+    print('near-zero PReLU inputs recorded:', sum(len(v) for k, v in kinks.items() if k.endswith('.idx')))
     print('g8_train_step.npz', os.path.getsize(os.path.join(HERE, 'g8_train_step.npz')), 'B')
 
     # ---- the oracle against the reference, right here -------------------------------------

@@ -114,6 +114,22 @@ def oracle_grads_on_masks(sd_r, fm, f_enc, label, masks, n):
     return {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(keys, grads)}, pre, [float(i.detach()) for i in items]
 
 
+def golden_side_masks(g8, pre, n):
+    """The side of every PReLU kink the REFERENCE's run (golden G8) was on: the oracle's own signs on this host, with
+    the elements the golden recorded as near zero (|x| < 1e-4 of the layer's largest) put on the golden's side -- any
+    host's fp32 rounding moves pre-activations by ~1e-6, so only recorded elements can differ."""
+    masks = {}
+    for k, x in pre.items():
+        m = (x > 0)
+        for gi, tag in enumerate(('non', 'ocl')):
+            part = m[gi * n:(gi + 1) * n].reshape(-1).clone()
+            idx = torch.from_numpy(g8['kink.%s.%s.idx' % (k, tag)])
+            part[idx] = torch.from_numpy(g8['kink.%s.%s.side' % (k, tag)])
+            m[gi * n:(gi + 1) * n] = part.reshape(m[gi * n:(gi + 1) * n].shape)
+        masks[k] = m
+    return masks
+
+
 def check_kinks(masks, pre, tol):
     """Every element whose side differs from the oracle's own lies within `tol` (relative to its layer's largest
     pre-activation) of zero.  -> number of such elements."""
@@ -220,10 +236,15 @@ def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir
         b = b if b is not None else torch.zeros(ref_shape)
         stacked.append(torch.cat([a, b]).cuda())
     g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
-    natural, pre, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], None, 4)
+    own, pre, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], None, 4)
     for k in tc['keys']:
-        assert grad_err(natural[k], tc['param_grads'][k]) < 1e-6     # the helper IS build_train_case's computation
-    for mode, tol, fwd_tol in ((0, 1e-4, 1e-5), (1, 3e-4, 1e-4)):
+        assert grad_err(own[k], tc['param_grads'][k]) < 1e-6     # the helper IS build_train_case's computation
+    # the oracle on the side of every kink the reference's run was on reproduces the golden's clipped gradients on THIS host
+    gmasks = golden_side_masks(g8, pre, 4)
+    print('%d near-zero PReLU inputs of this host\'s oracle run lie on the other side than in the golden\'s run'
+          % check_kinks(gmasks, pre, 1e-5))
+    natural, _, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], gmasks, 4)
+    for mode, tol, fwd_tol in ((0, 1e-4, 1e-5), (1, 1e-4, 1e-4)):      # measured: 7e-6 / 1.4e-5 (1 and 4 kinks transplanted)
         engine.train_init(tc['sd_r'])
         engine.train_option('winograd', mode)
         engine.train_forward(tc['fm'].cuda(), tc['label'].cuda(), groups=2, want=())
@@ -248,7 +269,7 @@ def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir
                 f = t.clamp(-1.0, 1.0).reshape(-1)
                 return f[::max(1, f.numel() // 64)][:64].double().cpu()
             expect = torch.from_numpy(d[2:]) + samples(ref[k]) - samples(natural[k])
-            scale = max(np.abs(d[2:]).max(), 1e-3)
+            scale = max(ref[k].abs().max().item(), 1e-3)          # the tensor's largest gradient, as for `e`
             assert (samples(got) - expect).abs().max().item() / scale < tol, (mode, k)
             asum = d[1] + ref[k].clamp(-1, 1).double().abs().sum().item() - natural[k].clamp(-1, 1).double().abs().sum().item()
             assert abs(got.clamp(-1.0, 1.0).double().abs().sum().item() - asum) <= tol * max(d[1], 1e-3 * got.numel()), (mode, k)
@@ -339,13 +360,13 @@ def test_native_trainer_step_matches_reference(specs, golden_dir):
     tr2 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
     items2 = tr2.step(non.cuda(), ocl.cuda(), label.cuda())
     assert np.allclose(np.array([float(l) for l in items2]), g8['losses'], rtol=1e-4)
-    check_iteration(3e-4, 1e-4, 'whole iteration, default (Winograd)')
+    check_iteration(1e-4, 1e-4, 'whole iteration, default (Winograd)')
     # the same iteration with the loss items evaluated by torch ops instead of the native loss kernels
     tr3 = ffrnet_amd.NativeTrainer(eng, sd_r, lr=float(g8['lr']))
     items3 = TL.step_torch_losses(tr3, non.cuda(), ocl.cuda(), label.cuda())
     assert np.allclose(np.array([float(l) for l in items3]), np.array([float(l) for l in items2]), rtol=1e-4)
     assert float(tr3.accuracy) == float(tr2.accuracy)
-    check_iteration(3e-4, 1e-4, 'whole iteration, default, torch loss items')
+    check_iteration(1e-4, 1e-4, 'whole iteration, default, torch loss items')
 
 
 def test_train_backward_kink_free_network_both_modes(engine, specs):
