@@ -19,6 +19,11 @@ struct WgradArgs {
     int rows, H, W, x_pitch, dy_pitch, cin_pad, taps, pad_mode, cout_pad;
     int Ng, mtiles, ntiles, nkt, splits, kt_per_split;    // set by the launcher
     int nbatch; long long dy_bstride, x_bstride, out_bstride, split_stride;   // set by the launcher
+    // tail split (batched launches, set by the launcher; tail_splits = 0: off): tiles [0, full_tiles) are whole rounds over the chip's
+    // block slots and run the full K range straight into `out`; each of the remaining tiles is cut into tail_splits blocks of tail_kt
+    // K-tiles that write tile-local partial sums [block][BM][BN] to tail_out, which k_wgrad_tail_reduce adds in a fixed order
+    int full_tiles, tail_splits, tail_kt;
+    float* tail_out;
 };
 // grad[cout_pad][taps*cin_pad] (+)= dy^T * gather(x); scratch holds the split-K slabs
 hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch, size_t scratch_floats,

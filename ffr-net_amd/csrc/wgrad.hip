@@ -14,6 +14,18 @@
 //
 // Split-K: the row range is cut into `splits` slabs out[split][cout_pad][Ng]; k_wgrad_reduce adds the
 // slabs in a fixed order (bitwise reproducible) and accumulates into / overwrites the gradient.
+//
+// Round 6, the batched launches (36 Winograd-domain products per layer, 576 / 1152 / 1728 equal blocks on 512 block slots):
+//  * TAIL SPLIT: 576 blocks are 1.125 rounds but RUN as 2 (0.56 of the chip).  The tiles of the whole rounds run the full K
+//    range as before; the tiles of the last, partial round are cut along K into as many blocks as fill the slots once
+//    (64 tiles x 8, 128 x 4, 192 x 2), write tile-local partial sums, and k_wgrad_tail_reduce adds them in a fixed order.
+//    Measured per 512 -> 512 launch at 128 pairs: 194 -> 159 + 8 us (a lone block per CU runs ~2x as fast as one of a pair, so the
+//    partial round was never a whole round: the gain is 15 %, not the 44 % the slot count suggests); 1152 blocks 323 -> 308 + 8,
+//    1728 blocks 452 -> 449 + 6 (profiles/r06_exp_wgrad_tail_split.txt).
+//  * PLAIN operands (rows are rows: the Winograd-domain products and the Linear layers) are staged through buffer
+//    resources: per-lane byte offset in one VGPR per DMA instruction, computed once; the K-tile advances the SCALAR offset
+//    (round 4 did the same for the operand streams of k_wino_fused; per-lane 64-bit pointers cost ~8 VALU instructions in
+//    front of every DMA, and every VALU instruction delays the wave's next MFMA by its issue time).
 #include "train_kernels.h"
 
 namespace ffr {
@@ -43,16 +55,33 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
     const int par = lane >> 5;                    // k parity this lane stages and reads
 
     int bid = blockIdx.x;
-    const int nt = bid % a.ntiles; bid /= a.ntiles;
-    const int mt = bid % a.mtiles; bid /= a.mtiles;
-    const int split = bid % a.splits;
-    const int batch = bid / a.splits;
+    int nt, mt, split, batch, kt0, kt1;
+    bool tile_local = false;                      // tail-split block: partial sums go to tail_out in tile-local layout
+    if (a.tail_splits > 0) {
+        int tile = bid;
+        kt0 = 0; kt1 = a.nkt; split = 0;
+        if (bid >= a.full_tiles) {
+            const int t = bid - a.full_tiles, q = t / a.tail_splits;
+            tile = a.full_tiles + q;
+            kt0 = (t - q * a.tail_splits) * a.tail_kt;
+            kt1 = kt0 + a.tail_kt;
+            tile_local = true;
+        }
+        nt = tile % a.ntiles; tile /= a.ntiles;
+        mt = tile % a.mtiles;
+        batch = tile / a.mtiles;
+    } else {
+        nt = bid % a.ntiles; bid /= a.ntiles;
+        mt = bid % a.mtiles; bid /= a.mtiles;
+        split = bid % a.splits;
+        batch = bid / a.splits;
+        kt0 = split * a.kt_per_split;
+        kt1 = kt0 + a.kt_per_split;
+    }
+    if (kt1 > a.nkt) kt1 = a.nkt;
     const float* const dyb = a.dy + (long long)batch * a.dy_bstride;
     const float* const xb = a.x + (long long)batch * a.x_bstride;
     const int co0 = mt * BM, n0 = nt * BN;
-    const int kt0 = split * a.kt_per_split;
-    int kt1 = kt0 + a.kt_per_split;
-    if (kt1 > a.nkt) kt1 = a.nkt;
 
     // this lane's 16-byte piece inside a staged row: position cpos, logical column chunk cl
     const int cposA = lane & (BM / 4 - 1);        // BM/4 pieces per row
@@ -67,10 +96,43 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
     const int dr = tap / 3 - (a.taps == 9 ? 1 : 0), ds = tap % 3 - (a.taps == 9 ? 1 : 0);
     const int HW = a.H * a.W;
 
+    // PLAIN: both operands through buffer resources (one per operand, based at this batch's matrix, `rows` rows long: a row
+    // beyond it reads zeros).  voff: this lane's byte offset inside a K-tile, per DMA instruction; everything else is scalar.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)dyb, 0, PLAIN ? (unsigned)a.rows * (unsigned)a.dy_pitch * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, PLAIN ? (unsigned)a.rows * (unsigned)a.x_pitch * 4u : 0u, 0x00020000);
+    unsigned voffA[A_INSTR], voffB[B_INSTR];
+    int krowA[A_INSTR], krowB[B_INSTR];
+#pragma unroll
+    for (int q = 0; q < A_INSTR; ++q) {
+        krowA[q] = ((q * 4 + wave) * 64 + lane) / (BM / 4);
+        voffA[q] = (unsigned)(krowA[q] * a.dy_pitch + co0 + clA * 4) * 4u;
+    }
+#pragma unroll
+    for (int q = 0; q < B_INSTR; ++q) {
+        krowB[q] = ((q * 4 + wave) * 64 + lane) / (BN / 4);
+        voffB[q] = jok ? (unsigned)(krowB[q] * a.x_pitch + ci) * 4u : OOB;
+    }
+
     auto stage_tile = [&](int buf, int kt) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + 32 * BM;
         const int m0 = kt * 32;
+        if constexpr (PLAIN) {
+            const unsigned soA = (unsigned)m0 * (unsigned)a.dy_pitch * 4u, soB = (unsigned)m0 * (unsigned)a.x_pitch * 4u;
+            const bool ragged = m0 + 32 > a.rows;         // only the last K-tile of a row count that is no multiple of 32
+#pragma unroll
+            for (int q = 0; q < A_INSTR; ++q) {
+                const unsigned v = ragged && m0 + krowA[q] >= a.rows ? OOB : voffA[q];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(sA + (q * 4 + wave) * 256), 16, v, soA, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < B_INSTR; ++q) {
+                const unsigned v = ragged && m0 + krowB[q] >= a.rows ? OOB : voffB[q];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(sB + (q * 4 + wave) * 256), 16, v, soB, 0, 0);
+            }
+            return;
+        }
         // dy tile: rows of BM floats; an instruction covers 64 pieces = 256 floats
 #pragma unroll
         for (int q = 0; q < A_INSTR; ++q) {
@@ -86,9 +148,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
             const int k = (piece + lane) / (BN / 4);
             const int m = m0 + k;
             const float* src = a.zero;
-            if (PLAIN) {
-                if (jok && m < a.rows) src = xb + (size_t)m * a.x_pitch + ci;
-            } else if (jok && m < a.rows) {
+            if (jok && m < a.rows) {
                 const int img = m / HW;
                 const int p = m - img * HW;
                 int h = p / a.W;
@@ -156,6 +216,21 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
         }
     }
     // accumulator layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (tile_local) {
+        float* out = a.tail_out + (size_t)(blockIdx.x - a.full_tiles) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const int col = wn * WN + jj * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * par;
+                    out[row * BN + col] = acc[i][jj][r];
+                }
+            }
+        return;
+    }
     float* out = a.out + (long long)split * a.split_stride + (long long)batch * a.out_bstride;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -172,22 +247,50 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(const WgradArgs a) {
         }
 }
 
-// grad[i] (+)= sum_s slabs[s][i]: 64 float4 outputs x 4 split lanes per block, fixed combination order
+// out tile (full_tiles + tt) = sum over its tail_splits partial tiles, in split order (bitwise reproducible); one float4 per thread,
+// BM * BN / 1024 blocks per tile
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_wgrad_tail_reduce(const WgradArgs a) {
+    constexpr int PER = BM * BN / 1024;
+    const int tt = blockIdx.x / PER, e = (blockIdx.x - tt * PER) * 256 + threadIdx.x;
+    int tile = a.full_tiles + tt;
+    const int nt = tile % a.ntiles; tile /= a.ntiles;
+    const int mt = tile % a.mtiles;
+    const int batch = tile / a.mtiles;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.tail_out + (size_t)tt * a.tail_splits * (BM * BN)) + e;
+    f32x4 s = src[0];
+    for (int sp = 1; sp < a.tail_splits; ++sp) s += src[(size_t)sp * (BM * BN / 4)];
+    const int row = e / (BN / 4), col = nt * BN + (e - row * (BN / 4)) * 4;
+    if (col < a.Ng) *reinterpret_cast<f32x4*>(a.out + (long long)batch * a.out_bstride + (size_t)(mt * BM + row) * a.Ng + col) = s;
+}
+
+// grad[i] (+)= sum_s slabs[s][i]: 256 / SL float4 outputs x SL split lanes per block, fixed combination order.
+// SL = 4 for a handful of slabs; SL = 32 where a small output is cut into hundreds of slabs (the Linear layers: 131072 rows, 2048
+// outputs, 512 slabs -- four lanes walking 128 slabs each took 40 us on 8 blocks)
+template <int SL>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, float* __restrict__ grad,
                                                      long long n4, int splits, int accumulate) {
-    __shared__ f32x4 sh[4][64];
-    const int t = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + t;
+    constexpr int NO = 256 / SL;
+    __shared__ f32x4 sh[SL][NO];
+    const int t = threadIdx.x % NO, sl = threadIdx.x / NO;
+    const long long i = (long long)blockIdx.x * NO + t;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (i < n4)
-        for (int k = sl; k < splits; k += 4) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
+        for (int k = sl; k < splits; k += SL) s += reinterpret_cast<const f32x4*>(slabs)[(long long)k * n4 + i];
     sh[sl][t] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && i < n4) {
-        s = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+    if (threadIdx.x < NO && i < n4) {
+        s = sh[0][t];
+#pragma unroll
+        for (int k = 1; k < SL; ++k) s += sh[k][t];
         if (accumulate) s += reinterpret_cast<const f32x4*>(grad)[i];
         reinterpret_cast<f32x4*>(grad)[i] = s;
     }
+}
+
+static void launch_reduce(const float* slabs, float* grad, long long n4, int splits, int accumulate, hipStream_t stream) {
+    if (splits > 16) hipLaunchKernelGGL(k_wgrad_reduce<32>, dim3((unsigned)((n4 + 7) / 8)), dim3(256), 0, stream, slabs, grad, n4, splits, accumulate);
+    else hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, slabs, grad, n4, splits, accumulate);
 }
 
 template <int BM, int BN>
@@ -226,11 +329,13 @@ hipError_t launch_wgrad(WgradArgs a, float* grad, int accumulate, float* scratch
     a.out = scratch;
     a.nbatch = 1; a.dy_bstride = 0; a.x_bstride = 0; a.out_bstride = 0;
     a.split_stride = (long long)per;
+    a.full_tiles = 0; a.tail_splits = 0; a.tail_kt = 0; a.tail_out = nullptr;
+    if (a.taps == 1 && a.H == 1 && a.W == 1 && ((double)a.rows * a.dy_pitch * 4.0 >= 2147483648.0 || (double)a.rows * a.x_pitch * 4.0 >= 2147483648.0))
+        return hipErrorInvalidValue;           // plain operands are read through 32-bit buffer offsets
     const unsigned grid = (unsigned)(tiles * splits);
     wgrad_dispatch(a, bm, bn, grid, a.taps == 1 && a.H == 1 && a.W == 1, stream);
     const long long n4 = (long long)per / 4;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, scratch, grad, n4, splits,
-                       accumulate);
+    launch_reduce(scratch, grad, n4, splits, accumulate, stream);
     return hipGetLastError();
 }
 
@@ -261,11 +366,32 @@ hipError_t launch_wgrad_batched(WgradArgs a, float* out, int nbatch, long long d
     a.out = splits > 1 ? scratch : out;
     a.nbatch = nbatch; a.dy_bstride = dy_bstride; a.x_bstride = x_bstride; a.out_bstride = (long long)a.cout_pad * a.Ng;
     a.split_stride = (long long)per;
+    a.full_tiles = 0; a.tail_splits = 0; a.tail_kt = 0; a.tail_out = nullptr;
+    if ((double)a.rows * a.dy_pitch * 4.0 >= 2147483648.0 || (double)a.rows * a.x_pitch * 4.0 >= 2147483648.0) return hipErrorInvalidValue;
+    // tail split: the blocks beyond the last whole round over the 512 block slots (2 per CU) are cut along K so that they fill the
+    // slots once instead of running as a round of their own
+    constexpr long long SLOTS = 512;
+    if (splits == 1 && blocks > SLOTS && blocks % SLOTS) {
+        const long long full = blocks / SLOTS * SLOTS, tail = blocks - full;
+        int ts = (int)(SLOTS / tail);
+        if (ts > a.nkt / 4) ts = a.nkt / 4;
+        while (ts >= 2 && (size_t)tail * ts * bm * 128 > scratch_floats) --ts;
+        if (ts >= 2) {
+            a.full_tiles = (int)full;
+            a.tail_kt = (a.nkt + ts - 1) / ts;
+            a.tail_splits = (a.nkt + a.tail_kt - 1) / a.tail_kt;
+            a.tail_out = scratch;
+            wgrad_dispatch(a, bm, 128, (unsigned)(full + tail * a.tail_splits), true, stream);
+            if (bm == 128) hipLaunchKernelGGL((k_wgrad_tail_reduce<128, 128>), dim3((unsigned)tail * 16), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_wgrad_tail_reduce<64, 128>), dim3((unsigned)tail * 8), dim3(256), 0, stream, a);
+            return hipGetLastError();
+        }
+    }
     const unsigned grid = (unsigned)(blocks * splits);
     wgrad_dispatch(a, bm, 128, grid, true, stream);
     if (splits > 1) {
         const long long n4 = (long long)per / 4;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, scratch, out, n4, splits, 0);
+        launch_reduce(scratch, out, n4, splits, 0, stream);
     }
     return hipGetLastError();
 }

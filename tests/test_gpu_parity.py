@@ -811,7 +811,7 @@ def test_bench_and_trainer_two_ranks_on_one_gpu():
     env.pop('WORLD_SIZE', None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # from a plain shell, as the driver calls it: bench.py spawns its own ranks
-    for extra, batch, scaling in ((['--batch', '16'], 16, 'weak'), (['--pairs-per-step', '24'], 24, 'strong')):
+    for extra, batch, scaling in ((['--batch', '16', '--strong-pairs', '40'], 16, 'weak'), (['--pairs-per-step', '24'], 24, 'strong')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
                '--no-roofline', '--no-cpu-baseline'] + extra
         out = _Sub.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
@@ -824,6 +824,17 @@ def test_bench_and_trainer_two_ranks_on_one_gpu():
         pr = d['per_rank']              # every rank reports its own clock and the collective's (one all-gather per step)
         assert len(pr['wall_ms_per_step']) == 2 and len(pr['all_gather_ms_hipevents_median']) == 2
         assert pr['all_gather_bytes_per_rank'] == 2 * batch * 512 * 4
+        if scaling == 'weak':
+            # the default N-GPU line also carries configs[3]'s STRONG-scaling shape (pairs per step split over the ranks) as a
+            # secondary entry, with every rank's all-gather time and the bytes it copied from host memory (its shard only)
+            (sec,) = d['secondary']
+            assert sec['scaling'] == 'strong' and sec['n_gpus'] == 2 and sec['batch_per_gpu'] == 40 and sec['value'] > 0
+            assert len(sec['per_rank']['all_gather_ms_hipevents_median']) == 2
+            fh = sec['from_host_memory']
+            assert fh['h2d_bytes_per_rank'] == fh['shard_bytes_per_rank'] == [2 * 2 * 20 * 3 * 112 * 112 * 4] * 2
+            assert fh['full_batch_bytes'] == 2 * 2 * 40 * 3 * 112 * 112 * 4
+        else:
+            assert d['secondary'] is None
     # eight handles + arenas + ranks side by side on one device (what an 8-GPU node runs, minus the links)
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '8',
            '--no-roofline', '--no-cpu-baseline']
