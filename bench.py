@@ -558,13 +558,6 @@ def train_workload(args, world, rank, local, dist):
         # tr.step() contains the gradient all-reduce, a COLLECTIVE: every rank runs the profiled iterations (a rank that
         # skipped them would leave rank 0 waiting in RCCL forever); only rank 0 instruments its launches and reports.
         roof = train_roofline(eng, lambda: tr.step(non, ocl, label), B, fence, instrument=(rank == 0))
-    if world > 1 and not strong and not args.no_secondary and args.strong_pairs > 0:
-        # the default N-GPU line is weak scaling (256 images per GPU); north_star's ">= 6x at 8 GPUs" is about configs[3], whose
-        # per-GPU batch SHRINKS with N: measured here in the same run, on every rank
-        entry = strong_scaling_line(eng, dist, world, rank, dev, min(args.steps, 20), min(args.warmup, 5), args.strong_pairs)
-        if rank == 0 and entry:
-            secondary = [entry]
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_train()
@@ -589,7 +582,7 @@ def main():
     # this image's host driver: with the legacy mode RCCL fails in hipIpcGetMemHandle ("invalid argument").  The image
     # exports HSA_ENABLE_IPC_MODE_LEGACY=0 already; a DEFAULT only (a caller's own setting wins), set at the one place
     # every launch mode passes through -- self-launched children inherit it, torch.distributed.run ranks and the
-    # single-rank run set it themselves here, before anything initialises the GPU runtime (DESIGN.md 3.4).
+    # single-rank run set it themselves here, before anything initialises the GPU runtime (DESIGN.md 6).
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -799,7 +792,7 @@ def main():
                 'gflop_useful_per_launch': round(dom['flops_useful'] / max(1, dom['launches']) / 1e9, 3),
                 'compulsory_gb_per_step': round(compulsory_gb, 3),
                 'traffic_detail': tr,
-                # what the kernel is co-limited by (DESIGN.md 3.2): operand fragments streamed L2 -> registers; a 32x64 tile
+                # what the kernel is co-limited by (DESIGN.md 3.1): operand fragments streamed L2 -> registers; a 32x64 tile
                 # per xi and 8-channel chunk moves (32 + 64) * 8 * 4 bytes for 2 * 32 * 64 * 8 flops
                 'operand_stream': {'bytes_per_flop': 0.09375,
                                    'tb_per_s': round(dom_tf * 0.09375, 2),
@@ -860,6 +853,12 @@ def main():
              'effective_tflops_algorithmic': round(B * GFLOP_TRUNK_96 / ms96['median'], 2)}]
         secondary.append(lfw_protocol_line(eng, dev))
         secondary.append(train_step_line(eng, sd_r, dev))
+    if world > 1 and not strong and not args.no_secondary and args.strong_pairs > 0:
+        # the default N-GPU line is weak scaling (256 images per GPU); north_star's ">= 6x at 8 GPUs" is about configs[3], whose
+        # per-GPU batch SHRINKS with N: measured here in the same run, on every rank
+        entry = strong_scaling_line(eng, dist, world, rank, dev, min(args.steps, 20), min(args.warmup, 5), args.strong_pairs)
+        if rank == 0 and entry:
+            secondary = [entry]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

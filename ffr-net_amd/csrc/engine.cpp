@@ -211,7 +211,7 @@ int wino_fused_choice(const ffr_handle* h, int cin_pad, int cout_pad, long long 
 }
 
 // True when the convolution WOULD run on the exact 4+4+3+3 tiling (k_wino_fused_mixed) once the three extra weight sets exist:
-// 14x14 map, zero padding, scratch large enough, and every CU gets at least two blocks (DESIGN.md 3.2).
+// 14x14 map, zero padding, scratch large enough, and every CU gets at least two blocks (DESIGN.md 3.1, 3.3).
 // wino_mode 4 forces it (tests, experiments; 7x7 maps = 4+3 too).
 bool wino_mixed_eligible(const ffr_handle* h, const ConvW& L, int N, int H, int W, int in_pitch, size_t wino_cap, int wino_mode) {
     if (!L.wuc || !L.w || L.R != 3 || L.S != 3 || L.stride != 1 || L.pad_mode != 0 || in_pitch != L.cin_pad) return false;

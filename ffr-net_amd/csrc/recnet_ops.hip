@@ -354,8 +354,10 @@ hipError_t launch_channel_path(const float* X, const ChannelPathWeights& w, floa
         attr_done = true;
     }
     if (row_blocks == 0) {
-        // one block per CU (113 KB of LDS): rounds x block time; block times measured on MI355X (us): whole image / half / quarter
-        const double t_block[3] = {181.0, 140.0, 101.0};     // profiles/r05_channel_path_phase_trace.txt
+        // one block per CU (147.6 of the CU's 160 KB of LDS): rounds x block time.  The block times (us: whole image / half / quarter of
+        // M_channel's rows) are MEASURED ON THE MI355X (profiles/r05_channel_path_phase_trace.txt) and only their ratios matter; this
+        // library runs on gfx950 only (ffr_create refuses other devices)
+        const double t_block[3] = {181.0, 140.0, 101.0};
         double best = 1e30;
         for (int k = 0; k < 3; ++k) {
             const int rb = 1 << k;

@@ -71,7 +71,7 @@ int layer_forward(ffr_handle* h, const Work& w, const TLayer& L, TSaved& sv, int
     ConvW cw;
     cw.cin = L.cin; cw.cin_pad = L.cin_pad; cw.cout = L.cout; cw.cout_pad = L.cout_pad; cw.R = 3; cw.S = 3; cw.stride = 1;
     cw.pad = 1; cw.pad_mode = 1; cw.border = 0; cw.w = L.w; cw.bias = h->zero; cw.slope = nullptr; cw.wu = nullptr;
-    // Winograd F(4x4,3x3) as the inference path (section 3.2 of DESIGN.md); U = G g G^T from the live weights
+    // Winograd F(4x4,3x3) as the inference path; U = G g G^T from the live weights
     const bool wino = s.wino && L.cin_pad >= 128 && s.U && (size_t)36 * L.cout_pad * L.cin_pad <= s.U_floats;
     // ... emitted in the order k_wino_fused streams when the launch can run fused (the kernel of the inference path: GEMMs +
     // output transform in one launch, raw convolution output for the batch statistics)
@@ -409,6 +409,10 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->sc.U_floats = (size_t)36 * 512 * 1536; t->sc.U = a.take(t->sc.U_floats);
         t->sc.canvas_floats = imgs * 64 * 512; t->sc.canvas = a.take(t->sc.canvas_floats);
         t->sc.edgeA_floats = imgs * 18 * 3 * 512; t->sc.edgeA = a.take(t->sc.edgeA_floats);
+        // the merged edge GEMM of layer_backward runs the column-8 problem with imgs * 9 rows: its last imgs rows of Er are never written
+        // by launch_dgrad_edges (their results land in rows nobody reads; run_gemm never mixes rows).  Zeroed once so that they hold finite,
+        // initialised values (the region is stable until the scratch is re-allocated)
+        HIPCK(h, hipMemset(t->sc.edgeA, 0, t->sc.edgeA_floats * sizeof(float)));
         t->sc.edgeW_floats = (size_t)2 * 1024 * 3 * 512; t->sc.edgeW = a.take(t->sc.edgeW_floats);
         t->sc.edgeO_floats = imgs * 18 * 1024; t->sc.edgeO = a.take(t->sc.edgeO_floats);
         t->dFeatNew = a.take(rows * 512); t->d512a = a.take(rows * 512); t->d512b = a.take(rows * 512);
@@ -728,6 +732,7 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
     s.U_floats = (size_t)36 * L.cout_pad * (L.cin_pad > need_pad ? L.cin_pad : need_pad); RC(dev_alloc_t(h, own, s.U_floats, &s.U));
     s.canvas_floats = (size_t)G * N * 64 * L.cout_pad; RC(dev_alloc_t(h, own, s.canvas_floats, &s.canvas));
     s.edgeA_floats = (size_t)G * N * 18 * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeA_floats, &s.edgeA));
+    HIPCK(h, hipMemset(s.edgeA, 0, s.edgeA_floats * sizeof(float)));      // see ensure_scratch
     s.edgeW_floats = (size_t)2 * need_pad * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeW_floats, &s.edgeW));
     s.edgeO_floats = (size_t)G * N * 18 * need_pad; RC(dev_alloc_t(h, own, s.edgeO_floats, &s.edgeO));
     RC(layer_forward(h, w, L, sv, G, N, nullptr, 0, out_nhwc, L.cout_pad, 0, 0, true, s, st));

@@ -21,7 +21,7 @@
 //
 // Epilogue: the 36 x 32 x 64 products of the block go through LDS in two passes of 32 channels (147 KB, which the K
 // loop does not use); a thread then owns (tile, 4 channels), applies A^T m A and the convolution epilogue and stores 16
-// bytes per pixel; a wave-store covers 8 tiles x 128 bytes.  DESIGN.md 3.2 has the measurements behind each choice.
+// bytes per pixel; a wave-store covers 8 tiles x 128 bytes.  DESIGN.md 3.1 states the design, EXPERIMENTS.md has the measurements behind each choice.
 #include "ffr_kernels.h"
 #include "wino_math.h"
 

@@ -8,7 +8,7 @@
 // channels, every xi, wave w owning S consecutive xi -- with S = 9 / 8 / 8 / 7 slots per wave (30 and 25 xi are padded to 32 and
 // 28 with zero weights), so a block of type (3,3) takes 7/9 of the K-loop time of a type (4,4) block.  All four types run in ONE
 // launch, blocks ordered by type: with two blocks per CU (batch 256: 128 blocks per type on 256 CUs) the CUs that ran (4,3) take
-// (3,4) and those that ran (4,4) take (3,3): 16 slots per CU where 16 padded F(4x4) tiles per image cost 18.
+// (3,4) and those that ran (4,4) take (3,3): 16 slots per CU where 16 padded F(4x4) tiles per image cost 18 (EXPERIMENTS.md, round 4).
 //
 //   k_wino_in_mixed    : X[N,H,W,pitch] --B_r^T d B_c--> V_type in the fragment order the GEMM streams, one region per type
 //   k_wino_fused_mixed : per block M[xi] = V[xi] U[xi]^T on the fp32 matrix cores, A_r^T M A_c + bias (border class) + PReLU

@@ -261,7 +261,7 @@ def test_batch_independence_other_batches(engine, state_dicts, B):
     branches than at 256 (32 x 32 block tiles of k_wino_fused for stage 3 / stage 4 / RecNet, 1.5-round launches).
     257: an odd batch on the exact 4+4+3+3 tiling of the 14x14 maps (wino_mixed.hip: the last tile group of every type is
     partly empty, the last combine block holds one image).  200 and 300: batches that are not a power of two -- the fused launches split off a different number of images for
-    the transform-kernel path (whole rounds of block tiles, DESIGN.md 3.2), tile groups straddle images, the last
+    the transform-kernel path (whole rounds of block tiles, DESIGN.md 3.1), tile groups straddle images, the last
     tile group is partly empty.  Every row must match the same image embedded in a batch of 8; a subset is held to
     the oracle."""
     sd_e, sd_r = state_dicts
@@ -355,6 +355,35 @@ def test_mixed_tile_weights_are_packed_lazily(state_dicts):
     f_new, _ = eng.embed(xb)                                              # batch 256 runs k_wino_fused_mixed on stage 3
     assert rel(f_new[:8].cpu(), f_new8.cpu()) < 2e-5
     assert eng.memory_stats()['mixed_tile_weight_bytes'] == st['mixed_tile_weight_bytes']      # packed once
+
+
+@pytest.mark.gpu
+def test_exact_tiling_with_512_channels_on_224x224_inputs(state_dicts):
+    """on a 224x224 input the 14x14 maps are STAGE 4 (512 channels), so the automatic path runs k_wino_fused_mixed,
+    k_combine_in_mixed and the SE tile sums with C = 512 -- a combination the 112x112 forward never reaches.  The trunk of 128
+    such images with the exact tiling equals the padded-tile run of the same handle (another arithmetic, so not bitwise) and the
+    oracle on two of them; the weight sets are derived per layer from the real input size (stage 3 runs 28x28 here: none for it)."""
+    sd_e, _ = state_dicts
+    eng = ffrnet_amd.Engine(0)
+    eng.load_encoder(sd_e)
+    x = synth.synth_images(128, 224, 224, seed=41)
+    xd = x.cuda()
+    a = eng.encoder_trunk_nhwc(xd, 24)
+    st = eng.memory_stats()
+    assert 0 < st['mixed_tile_weight_bytes'] < 0.5e9           # the 5 stride-1 convolutions of stage 4: 512 -> 512
+    eng.set_option('wf_mixed', 0)
+    b = eng.encoder_trunk_nhwc(xd, 24)
+    torch.cuda.synchronize()
+    assert list(a.shape) == [128, 14, 14, 512]
+    assert rel(a, b) < 2e-5 and not torch.equal(a, b)
+    with torch.no_grad():
+        ref = O.encoder_trunk(sd_e, x[:2], 24)
+    assert rel(a[:2].permute(0, 3, 1, 2), ref) < REG_TOL
+    # alternating input shapes on one handle: the 112x112 forward still finds (and now derives) its own layers' sets
+    eng.set_option('wf_mixed', 1)
+    eng.reserve(256)
+    assert eng.memory_stats()['mixed_tile_weight_bytes'] > st['mixed_tile_weight_bytes']
+    eng.close()
 
 
 @pytest.mark.parametrize('B', [256, 512])
@@ -873,7 +902,7 @@ def test_rccl_one_rank_runs_the_product_collectives():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # a default, as in bench.py main(): dmabuf IPC handles (DESIGN.md 3.4)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # a default, as in bench.py main(): dmabuf IPC handles (DESIGN.md 6)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_one_rank.py')], cwd=root, env=env,

@@ -1,7 +1,7 @@
 // k_wino_fused_q: the Winograd F(4x4,3x3) convolution with in-kernel input transform (cin <= 128; reference convolutions
 // pretrain/model_ir_se50.py:67,69) in the form where a wave owns ALL 36 xi of a 32-tile x 16-channel slice.
 // Round-4 experiment, selected by the option "wf_q", OFF by default: it is as fast as
-// k_wino_fused<1, 2> and not faster (DESIGN.md 3.2 has the phase table); kept as the worked example of the form.
+// k_wino_fused<1, 2> and not faster (EXPERIMENTS.md 3.2 has the phase table); kept as the worked example of the form.
 //
 // k_wino_fused<1, 2> (wino_fused.hip) gives wave w the xi in [9w, 9w + 9) for all 32 tiles x 64 channels: the 36 values of
 // one (tile, channel) end up in four waves, so the output transform A^T m A needs the block-wide E[xi][tile][channel]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Vector-memory front-end counters (texture addresser TA, L1 TCP) per kernel of one forward at batch 256 -- the hardware
-# evidence for DESIGN.md 3.2 "cost model".  Separate --pmc passes; run via gpurun, copy the summary into profiles/.
+# evidence for EXPERIMENTS.md 3.2 "cost model".  Separate --pmc passes; run via gpurun, copy the summary into profiles/.
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
 R="$GRAFT_REPO_ROOT"

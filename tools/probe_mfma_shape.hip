@@ -14,7 +14,9 @@
 // on 256 CUs.  Reported per arm: TFLOP/s by wall (hipEvents over all launches), cycles per K chunk, and the in-kernel
 // clock  d s_memtime / d s_memrealtime x 100 MHz  (median over the blocks of the last launch).
 // Arms: with the operand loads / bare (operands held in registers); shape 1 also with its three loads spread over
-// three gaps (it has twice the gaps).
+// three gaps (it has twice the gaps); and with the V fragment of every step streamed from BEYOND the L2 as in the product
+// (36 KB per K chunk and tile group, shared by the four channel-group blocks of the group): from a 151 MB region that stays
+// in the 256 MB Infinity Cache between launches, and from 20 such regions in rotation (HBM).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -29,9 +31,12 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define PIN __builtin_amdgcn_sched_barrier(0)
 
 // SHAPE 0: 32x32x2, 1: 16x16x4.  LOADS 0: none, 1: three per step in one gap, 2: one in each of three gaps.
-template <int SHAPE, int LOADS>
+// VBIG: the V fragment (one of the three per step) comes from `big` instead: 36 KB per K chunk and group of four blocks (the four
+// channel groups of a tile group read the same V), `big_off` rotates the region between launches (HBM) or stays (Infinity Cache)
+template <int SHAPE, int LOADS, bool VBIG = false>
 __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ stream, unsigned stream_bytes, int nkc,
-                                                   unsigned long long* __restrict__ stamps, float* __restrict__ sink) {
+                                                   unsigned long long* __restrict__ stamps, float* __restrict__ sink,
+                                                   const float* __restrict__ big = nullptr, unsigned long long big_off = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, stream_bytes, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -39,6 +44,11 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
     unsigned sp = (unsigned)(wave * 27 + (blockIdx.x & 7) * 108) * 1024u;
     const unsigned wrap = stream_bytes - 2u * 27u * 1024u * 5u;
     auto ldfrag = [&](unsigned so) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, so, 0)); };
+    // V of this block's tile group: [K chunk][36 xi][64 lanes][4], this wave's 9 xi
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)big + big_off + (size_t)(blockIdx.x >> 2) * nkc * 36864u), 0,
+                                                                        VBIG ? (unsigned)nkc * 36864u : 0u, 0x00020000);
+    unsigned vp = (unsigned)wave * 9u * 1024u;
+    auto ldv = [&](unsigned so) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, lane16, so, 0)); };
 
     f32x4 fr[9][3];                      // slot j: the three 16-byte fragments of xi j
     // accumulators: xi 0..7 through the builtin (AGPRs), xi 8 through the VGPR form (a wave has 256 AGPRs)
@@ -59,19 +69,22 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc16[j][t][r] = 0.f; }
     }
-    auto load = [&](int j, int part, unsigned base) { fr[j][part] = ldfrag(base + (unsigned)(j * 3 + part) * 1024u); };
+    auto load = [&](int j, int part, unsigned base, unsigned vbase) {
+        if (VBIG && part == 0) fr[j][part] = ldv(vbase + (unsigned)j * 1024u);
+        else fr[j][part] = ldfrag(base + (unsigned)(j * 3 + part) * 1024u);
+    };
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
-            if (LOADS == 0 || j < 8) load(j, part, sp);           // bare arms: random operands too, loaded once
+            if (LOADS == 0 || j < 8) load(j, part, sp, vp);       // bare arms: random operands too, loaded once
             else fr[j][part] = f32x4{0.f, 0.f, 0.f, 0.f};         // slot 8 is requested in step 0 of every chunk
         }
         PIN;
     }
     PIN;
     unsigned long long t0 = 0, r0 = 0;
-    if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (lane == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }      // every wave stamps its own loop
     __builtin_amdgcn_s_waitcnt(0xC07F);
 
     auto chunk = [&]<bool LAST>() {
@@ -98,8 +111,8 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
                     for (int part = 0; part < 3; ++part) {
                         const bool here = LOADS == 1 ? g == 1 : g == 1 + 2 * part;
                         if (here) {
-                            if (j == 0) load(8, part, sp);
-                            else if (!LAST) load(j - 1, part, sp + 27u * 1024u * 4u);
+                            if (j == 0) load(8, part, sp, vp);
+                            else if (!LAST) load(j - 1, part, sp + 27u * 1024u * 4u, vp + 36864u);
                         }
                     }
                 }
@@ -112,14 +125,15 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
         chunk.template operator()<false>();
         sp += 27u * 1024u * 4u;                 // the four waves' fragments of one chunk are contiguous: 108 KB per chunk
         if (sp >= wrap) sp -= wrap;
+        vp += 36864u;
     }
     chunk.template operator()<true>();
     asm volatile("s_nop 7\ns_nop 7" ::: "memory");
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        stamps[blockIdx.x * 4 + 0] = t0; stamps[blockIdx.x * 4 + 1] = t1;
-        stamps[blockIdx.x * 4 + 2] = r0; stamps[blockIdx.x * 4 + 3] = r1;
+        unsigned long long* st = stamps + (size_t)(blockIdx.x * 4 + wave) * 4;
+        st[0] = t0; st[1] = t1; st[2] = r0; st[3] = r1;
     }
     float s = 0.f;
     if constexpr (SHAPE == 0) {
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
     sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-struct Arm { const char* name; void (*fn)(const float*, unsigned, int, unsigned long long*, float*); int shape; };
+struct Arm { const char* name; void (*fn)(const float*, unsigned, int, unsigned long long*, float*, const float*, unsigned long long); int shape; int vmode; };
 
 static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
@@ -150,17 +164,25 @@ int main(int argc, char** argv) {
     const bool zeros = argc > 4 && atoi(argv[4]) != 0;
     const unsigned stream_bytes = 2u << 20;           // 2 MB: inside one XCD's 4 MB L2
     float *stream, *sink; unsigned long long* stamps;
-    CK(hipMalloc(&stream, stream_bytes)); CK(hipMalloc(&sink, (size_t)blocks * 256 * 4)); CK(hipMalloc(&stamps, (size_t)blocks * 32));
+    CK(hipMalloc(&stream, stream_bytes)); CK(hipMalloc(&sink, (size_t)blocks * 256 * 4)); CK(hipMalloc(&stamps, (size_t)blocks * 128));
     std::vector<float> h(stream_bytes / 4);
     unsigned s = 12345u;
     for (auto& x : h) { s = s * 1664525u + 1013904223u; x = zeros ? 0.f : ((float)(s >> 8) / 8388608.f - 1.0f); }
     CK(hipMemcpy(stream, h.data(), stream_bytes, hipMemcpyHostToDevice));
+    // V region: 36 KB per K chunk and group of four blocks; 20 such regions side by side for the rotating arm
+    const size_t region = (size_t)(blocks / 4 + 1) * nkc * 36864u, nreg = 20;
+    float* big; CK(hipMalloc(&big, region * nreg));
+    for (size_t o = 0; o < region * nreg; o += stream_bytes) CK(hipMemcpy((char*)big + o, stream, std::min((size_t)stream_bytes, region * nreg - o), hipMemcpyDeviceToDevice));
+    printf("# V region %.1f MB per launch, %zu regions\n", region / 1048576.0, nreg);
     const Arm arms[] = {
-        {"32x32x2  + 27 loads/chunk (3 in one gap)  ", k_chunks<0, 1>, 0},
-        {"16x16x4  + 27 loads/chunk (3 in one gap)  ", k_chunks<1, 1>, 1},
-        {"16x16x4  + 27 loads/chunk (1 in each of 3)", k_chunks<1, 2>, 1},
-        {"32x32x2  bare (operands in registers)     ", k_chunks<0, 0>, 0},
-        {"16x16x4  bare (operands in registers)     ", k_chunks<1, 0>, 1},
+        {"32x32x2  + 27 loads/chunk (3 in one gap)  ", k_chunks<0, 1>, 0, 0},
+        {"16x16x4  + 27 loads/chunk (3 in one gap)  ", k_chunks<1, 1>, 1, 0},
+        {"16x16x4  + 27 loads/chunk (1 in each of 3)", k_chunks<1, 2>, 1, 0},
+        {"32x32x2  bare (operands in registers)     ", k_chunks<0, 0>, 0, 0},
+        {"16x16x4  bare (operands in registers)     ", k_chunks<1, 0>, 1, 0},
+        {"32x32x2  V from a 151 MB region (Inf.Cache)", k_chunks<0, 1, true>, 0, 1},
+        {"32x32x2  V from HBM (3 GB, rotating)       ", k_chunks<0, 1, true>, 0, 2},
+        {"16x16x4  V from HBM, loads spread          ", k_chunks<1, 2, true>, 1, 2},
     };
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("# %s, %d CUs; %d blocks x 256 threads, %d K chunks per block, %.1f s per arm, %s operands\n", prop.gcnArchName,
@@ -170,27 +192,39 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep)
         for (const Arm& a : arms) {
             // warm up, then >= `seconds` of back-to-back launches
-            for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(a.fn, dim3(blocks), dim3(256), 0, 0, stream, stream_bytes, nkc, stamps, sink);
+            auto off = [&](int i) { return (unsigned long long)(a.vmode == 2 ? (size_t)(i % nreg) * region : 0); };
+            for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(a.fn, dim3(blocks), dim3(256), 0, 0, stream, stream_bytes, nkc, stamps, sink, big, off(i));
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(a.fn, dim3(blocks), dim3(256), 0, 0, stream, stream_bytes, nkc, stamps, sink);
+            hipLaunchKernelGGL(a.fn, dim3(blocks), dim3(256), 0, 0, stream, stream_bytes, nkc, stamps, sink, big, off(0));
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float one; CK(hipEventElapsedTime(&one, e0, e1));
             const int n = std::max(20, (int)(seconds * 1e3 / one));
             CK(hipEventRecord(e0));
-            for (int i = 0; i < n; ++i) hipLaunchKernelGGL(a.fn, dim3(blocks), dim3(256), 0, 0, stream, stream_bytes, nkc, stamps, sink);
+            for (int i = 0; i < n; ++i) hipLaunchKernelGGL(a.fn, dim3(blocks), dim3(256), 0, 0, stream, stream_bytes, nkc, stamps, sink, big, off(i));
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            std::vector<unsigned long long> st((size_t)blocks * 4);
+            std::vector<unsigned long long> st((size_t)blocks * 16);
             CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
-            std::vector<double> cyc, mhz;
+            // per block: the SLOWEST of its four waves (the block ends with it); clock from wave 0's two counters
+            std::vector<double> cyc, cyc0, mhz, loop_us;
             for (int b = 0; b < blocks; ++b) {
-                const double dc = (double)(st[b * 4 + 1] - st[b * 4 + 0]), dr = (double)(st[b * 4 + 3] - st[b * 4 + 2]);
-                cyc.push_back(dc / nkc); mhz.push_back(dr > 0 ? dc / dr * 100.0 : 0.0);
+                double worst = 0, worst_rt = 0;
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned long long* q = &st[(size_t)(b * 4 + w) * 4];
+                    worst = std::max(worst, (double)(q[1] - q[0]));
+                    worst_rt = std::max(worst_rt, (double)(q[3] - q[2]));
+                }
+                const unsigned long long* q0 = &st[(size_t)b * 16];
+                const double dc = (double)(q0[1] - q0[0]), dr = (double)(q0[3] - q0[2]);
+                cyc.push_back(worst / nkc); cyc0.push_back(dc / nkc); mhz.push_back(dr > 0 ? dc / dr * 100.0 : 0.0);
+                loop_us.push_back(worst_rt * 0.01);
             }
             const double flop = 294912.0 * 4 * nkc * blocks * (double)n;
-            printf("rep %d  %s  %7.2f TFLOP/s by wall  %8.1f us/launch  %7.0f cycles/K-chunk  clock %6.0f MHz  (%d launches)\n", rep, a.name,
-                   flop / (ms * 1e-3) * 1e-12, ms * 1e3 / n, median(cyc), median(mhz), n);
+            // loop TFLOP/s: the K loops alone (prologue / accumulator read-out excluded), two blocks per CU one after the other
+            const double loop_tf = 294912.0 * 4 * nkc * blocks / (2.0 * median(loop_us) * 1e-6) * 1e-12;
+            printf("rep %d  %s  %7.2f TFLOP/s by wall  %7.1f us/launch | K loop: %6.1f us/block = %6.2f TFLOP/s, %5.0f cycles/chunk (wave 0: %5.0f)  clock %5.0f MHz  (%d launches)\n",
+                   rep, a.name, flop / (ms * 1e-3) * 1e-12, ms * 1e3 / n, median(loop_us), loop_tf, median(cyc), median(cyc0), median(mhz), n);
             fflush(stdout);
         }
     return 0;
