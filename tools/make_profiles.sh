@@ -1,10 +1,10 @@
 #!/bin/bash
-# Measurement artefacts of one round (run via gpurun from the repo root):  bash tools/make_profiles.sh r05
+# Measurement artefacts of one round (run via gpurun from the repo root, ONCE, after the kernels are frozen):  bash tools/make_profiles.sh r06
 # Writes gpurun_out/<round>/<round>_*; the PMC summary is installed under profiles/ ONLY when every counter pass succeeded
 # and its so_sha256 is the hash of the library in the tree.
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the root of the snapshot)}"
-RD="${1:-r05}"
+RD="${1:-r06}"
 R="$GRAFT_REPO_ROOT"
 O="$R/gpurun_out/$RD"
 rm -rf -- "$O"; mkdir -p -- "$O"
@@ -28,17 +28,14 @@ for b in 128 64; do
   python3 bench.py --batch $b --no-cpu-baseline --no-secondary > "$O/${RD}_bench_batch$b.json" 2>> "$O/bench.err" || echo "bench$b rc $?"
 done
 python3 bench.py --pairs-per-step 512 --no-cpu-baseline --no-secondary > "$O/${RD}_bench_pairs512_1gpu.json" 2>> "$O/bench.err" || true
-FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --pairs-per-step 512 --no-roofline --no-cpu-baseline 2>> "$O/bench.err" | grep '^{' > "$O/${RD}_bench_selflaunch_2ranks_gloo_one_device.json" || true
+# the driver's flag-less N-GPU call on ONE device over gloo: the weak-scaling line + its strong-scaling `secondary` entry (timings mean nothing)
+FFR_BENCH_BACKEND=gloo FFR_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-roofline --no-cpu-baseline 2>> "$O/bench.err" | grep '^{' > "$O/${RD}_bench_selflaunch_2ranks_gloo_one_device.json" || true
 python3 bench.py --workload train > "$O/${RD}_train_step.json" 2>> "$O/bench.err" || true
 python3 tools/wf_trace.py 2>&1 | grep "wf trace" > "$O/wf_trace_all.txt" || true
 grep -E "mixed|type \(|CUs ran" "$O/wf_trace_all.txt" > "$O/${RD}_wino_mixed_phase_trace.txt" || true
 grep "k_channel_path" "$O/wf_trace_all.txt" > "$O/${RD}_channel_path_phase_trace.txt" || true
 grep -v -E "mixed|type \(|CUs ran|k_channel_path" "$O/wf_trace_all.txt" > "$O/${RD}_wino_fused_phase_trace.txt" || true
 B=64 python3 tools/wf_trace.py 2>&1 | grep "k_channel_path" >> "$O/${RD}_channel_path_phase_trace.txt" || true
-python3 tools/mixed7_experiment.py 2>/dev/null | grep -v "amdgpu.ids" > "$O/${RD}_exp_mixed_tiling_7x7_and_14x14.txt" || true
-[ -x build/probe_launch_gap ] && build/probe_launch_gap > "$O/${RD}_probe_kernel_boundary_gap.txt" 2>&1 || true
-for cr in 1 2 4; do for b in 128 64; do python3 bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --opt channel_rows=$cr > "$O/${RD}_exp_bench_batch${b}_channel_rows$cr.json" 2>> "$O/bench.err" || true; done; done
-for m in 1 0; do python3 bench.py --batch 128 --no-cpu-baseline --no-secondary --opt wf_mixed=$m > "$O/${RD}_exp_bench_batch128_wf_mixed$m.json" 2>> "$O/bench.err" || true; done
 TRACE=igemm_trace python3 tools/wf_trace.py 2>&1 | grep "igemm trace" > "$O/${RD}_igemm_trace.txt" || true
 cd /tmp && export TMPDIR=/tmp
 export FFR_BENCH_LIVE_PMC=0      # runs under rocprofv3 never start profiler passes of their own (bench.py also detects the profiler)
