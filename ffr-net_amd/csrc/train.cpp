@@ -409,10 +409,6 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
         t->sc.U_floats = (size_t)36 * 512 * 1536; t->sc.U = a.take(t->sc.U_floats);
         t->sc.canvas_floats = imgs * 64 * 512; t->sc.canvas = a.take(t->sc.canvas_floats);
         t->sc.edgeA_floats = imgs * 18 * 3 * 512; t->sc.edgeA = a.take(t->sc.edgeA_floats);
-        // the merged edge GEMM of layer_backward runs the column-8 problem with imgs * 9 rows: its last imgs rows of Er are never written
-        // by launch_dgrad_edges (their results land in rows nobody reads; run_gemm never mixes rows).  Zeroed once so that they hold finite,
-        // initialised values (the region is stable until the scratch is re-allocated)
-        HIPCK(h, hipMemset(t->sc.edgeA, 0, t->sc.edgeA_floats * sizeof(float)));
         t->sc.edgeW_floats = (size_t)2 * 1024 * 3 * 512; t->sc.edgeW = a.take(t->sc.edgeW_floats);
         t->sc.edgeO_floats = imgs * 18 * 1024; t->sc.edgeO = a.take(t->sc.edgeO_floats);
         t->dFeatNew = a.take(rows * 512); t->d512a = a.take(rows * 512); t->d512b = a.take(rows * 512);
@@ -432,6 +428,9 @@ int ensure_scratch(ffr_handle* h, TrainState* t, int imgs_i) {
     const size_t need = carve(nullptr);
     if (hipMalloc(&t->scratch_mem, need) != hipSuccess) { t->scratch_mem = nullptr; return fail(h, FFR_ERR_NOMEM, "hipMalloc of %zu training-scratch bytes failed", need); }
     carve((char*)t->scratch_mem);
+    // zeroed once, all of it: the merged edge GEMM of layer_backward runs the column-8 problem with imgs * 9 rows, and the last imgs rows of
+    // its operand Er are never written by launch_dgrad_edges (their results land in rows nobody reads; run_gemm never mixes rows) -- they
+    // hold initialised, finite values from here on
     HIPCK(h, hipMemset(t->scratch_mem, 0, need));
     t->scratch_imgs = imgs_i;
     return FFR_OK;
@@ -732,7 +731,7 @@ int ffr_op_convlayer_train(ffr_handle* h, const float* x_nhwc, int G, int N, int
     s.U_floats = (size_t)36 * L.cout_pad * (L.cin_pad > need_pad ? L.cin_pad : need_pad); RC(dev_alloc_t(h, own, s.U_floats, &s.U));
     s.canvas_floats = (size_t)G * N * 64 * L.cout_pad; RC(dev_alloc_t(h, own, s.canvas_floats, &s.canvas));
     s.edgeA_floats = (size_t)G * N * 18 * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeA_floats, &s.edgeA));
-    HIPCK(h, hipMemset(s.edgeA, 0, s.edgeA_floats * sizeof(float)));      // see ensure_scratch
+    HIPCK(h, hipMemset(s.edgeA, 0, s.edgeA_floats * sizeof(float)));      // the unwritten tail rows of Er: see ensure_scratch
     s.edgeW_floats = (size_t)2 * need_pad * 3 * L.cout_pad; RC(dev_alloc_t(h, own, s.edgeW_floats, &s.edgeW));
     s.edgeO_floats = (size_t)G * N * 18 * need_pad; RC(dev_alloc_t(h, own, s.edgeO_floats, &s.edgeO));
     RC(layer_forward(h, w, L, sv, G, N, nullptr, 0, out_nhwc, L.cout_pad, 0, 0, true, s, st));
