@@ -704,6 +704,15 @@ def test_stress_families_vs_reference(specs, golden_dir, fam):
     check('featmap0', featmap[0], 'featmap0')
     check('feat_new0', feat_new[0], 'feat_new0')
     assert rel(f_new2, f_new) < 1e-6 and rel(f2, f) < 1e-6              # fused entry point == two-call path
+    # the same 8 images as rows 0..7 of a batch of 256: only there do stage 3's 27 convolutions run the EXACT tiling
+    # (k_wino_fused_mixed / k_combine_in_mixed: F(4x3), F(3x4), F(3x3) tile types, other interpolation points) and the 32 x 64 block shape
+    xb = synth.synth_images(256, 112, 112, seed=img_seed + 500)
+    xb[:8] = x
+    fb_new, fb = eng.embed(xb.cuda())
+    torch.cuda.synchronize()
+    assert eng.memory_stats()['mixed_tile_weight_bytes'] > 0.5e9
+    check('f (rows 0..7 of batch 256)', fb[:8], 'f')
+    check('f_new (rows 0..7 of batch 256)', fb_new[:8], 'f_new')
     for nb, name in STRESS_TAPS:
         got = eng.encoder_trunk_nhwc(xd[:1].contiguous(), nb).permute(0, 3, 1, 2)[0].reshape(-1)
         step = max(1, got.numel() // 256)
