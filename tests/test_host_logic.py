@@ -116,22 +116,50 @@ def test_integration_lists_the_sources():
 
 def test_committed_profiles_agree_with_their_bench_lines():
     """The round's committed measurement set is self-consistent: tools/roofline_check.py recomputes the roofline block of
-    profiles/r05_bench.json from the rocprofv3 summary next to it (launches, average launch time, executed / useful FLOPs from a layer
-    table, the three fractions) and the training classes of profiles/r05_train_step.json from theirs; and the PMC summary bench.py
+    profiles/r06_bench.json from the rocprofv3 summary next to it (launches, average launch time, executed / useful FLOPs from a layer
+    table, the three fractions) and the training classes of profiles/r06_train_step.json from theirs; and the PMC summary bench.py
     would quote carries the hash of the same build as the bench line."""
     import json
     prof = os.path.join(ROOT, 'profiles')
     for extra in ([], ['--train']):
-        stats = 'r05_train_step_kernel_stats.csv' if extra else 'r05_bench_batch256_kernel_stats.csv'
-        line = 'r05_train_step.json' if extra else 'r05_bench.json'
+        stats = 'r06_train_step_kernel_stats.csv' if extra else 'r06_bench_batch256_kernel_stats.csv'
+        line = 'r06_train_step.json' if extra else 'r06_bench.json'
         out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'roofline_check.py')] + extra +
                              [os.path.join(prof, stats), os.path.join(prof, line)], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
-    bench = json.loads([l for l in open(os.path.join(prof, 'r05_bench.json')) if l.startswith('{')][-1])
-    pmc = json.load(open(os.path.join(prof, 'r05_pmc_hbm_traffic.json')))
+    bench = json.loads([l for l in open(os.path.join(prof, 'r06_bench.json')) if l.startswith('{')][-1])
+    pmc = json.load(open(os.path.join(prof, 'r06_pmc_hbm_traffic.json')))
     assert pmc['so_sha256'] == bench['roofline']['so_sha256'] and pmc['batch'] == 256
     assert abs(bench['roofline']['traffic_ratio_vs_compulsory'] - pmc['gb_per_step'] / (14.3 + 0.2732)) < 0.01
     assert bench['secondary'][-1]['unit'] == 'pairs/s' and bench['secondary'][-1]['ms_per_iteration'] > 0       # the training line (VERDICT r04 #2)
+
+
+def test_design_documents_and_option_table_stay_in_shape():
+    """DESIGN.md is the CURRENT design (<= 300 lines), the lab notebook lives in EXPERIMENTS.md and its index
+    names every profiles/r0N_exp_* artefact exactly once; the handle has <= 18 options and include/ffrnet.h documents each of them
+    (and none that is gone)."""
+    design = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    assert design.count('\n') <= 300
+    exp = open(os.path.join(ROOT, 'EXPERIMENTS.md')).read()
+    index = exp[exp.index('## Index of experiment artefacts'):exp.index('## Round 6')]
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if re.match(r'r0\d_exp_', f))
+    assert files, 'no experiment artefacts found'
+    for f in files:
+        assert index.count('`%s`' % f) == 1, f
+    assert len(re.findall(r'^\| `r0\d_exp_', index, re.M)) == len(files)          # and no row for a file that does not exist
+    eng = open(os.path.join(ROOT, 'ffr-net_amd', 'csrc', 'engine.cpp')).read()
+    table = eng[eng.index('const OptEntry OPTIONS[] = {'):]
+    table = table[:table.index('};')]
+    names = re.findall(r'\{"(\w+)"', table)
+    assert 10 <= len(names) <= 18 and len(set(names)) == len(names)
+    header = open(os.path.join(ROOT, 'include', 'ffrnet.h')).read()
+    doc = header[header.index('Experiment knobs of one handle'):header.index('int ffr_set_option')]
+    for n in names:
+        assert '"%s"' % n in doc, n
+    for gone in ('wino_112', 'wf_halfblocks', 'wf_mapv', 'wf_mapx', 'wf_maph', 'wm_xcdpairs', 'wino_slice_mb', 'gs_tile', 'wino_oi',
+                 'se_fuse', 'igemm_tile64'):
+        assert '"%s"' % gone not in doc and gone not in names
+    assert 'FFR_WF_NPRE' not in open(os.path.join(ROOT, 'ffr-net_amd', 'csrc', 'wino_fused.hip')).read()
 
 
 def test_weight_cache_sees_submodule_surgery():
