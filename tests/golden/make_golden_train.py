@@ -2,7 +2,10 @@
 """Generate tests/golden/g8_train_step.npz by running THE REFERENCE's own training-step code on CPU.
 
 Run in the build container only (needs /root/reference, which never travels):
-    python tests/golden/make_golden_train.py
+    python tests/golden/make_golden_train.py              # G8: the benign weights of G1-G10
+    python tests/golden/make_golden_train.py kaiming      # G12 (g12_train_step_kaiming.npz): the weights a training run STARTS from --
+                                                          # RecNet as init_weights(self.recnet, 'kaiming') leaves it (models/trainer.py:65-66)
+                                                          # behind the trained-like encoder of golden G11 (synth.STRESS_FAMILIES['kaiming'])
 What runs is the reference's RecNet (train mode), AddMarginProduct head, Trainer.forward,
 Trainer.backward, clip_grad_value_ and torch.optim.Adam (models/trainer.py:139-187) on 4 seeded
 synthetic pairs with the synthetic weights of ffr-net_amd/synth.py.  Stored: the 7-tuple outputs,
@@ -41,7 +44,7 @@ def digest(t, n=64):
                            strided(t, n).double().numpy()]).astype(np.float64)
 
 
-def main():
+def main(family=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     _stub = types.ModuleType('utils_stub')  # noqa: F841
@@ -52,8 +55,12 @@ def main():
     rec = m_rec.RecNet(channel=512, shape=7, norm_type='bn', relu_type='prelu')
     spec_e = {k: list(v.shape) for k, v in enc.state_dict().items()}
     spec_r = {k: list(v.shape) for k, v in rec.state_dict().items()}
-    enc.load_state_dict(synth.synth_state_dict(spec_e, seed=0))
-    rec.load_state_dict(synth.synth_state_dict(spec_r, seed=0))
+    if family:
+        sd_e0, sd_r0 = synth.stress_state_dicts(family, spec_e, spec_r, HERE)
+    else:
+        sd_e0, sd_r0 = synth.synth_state_dict(spec_e, seed=0), synth.synth_state_dict(spec_r, seed=0)
+    enc.load_state_dict(sd_e0)
+    rec.load_state_dict(sd_r0)
     for p in enc.parameters():
         p.requires_grad = False
 
@@ -124,15 +131,18 @@ def main():
             g8['after.' + k] = after[k].numpy().astype(np.float64)
         if k.endswith('num_batches_tracked'):
             assert int(after[k]) == int(before[k]) + 2
-    np.savez_compressed(os.path.join(HERE, 'g8_train_step.npz'), **g8)
+    out_name = 'g12_train_step_%s.npz' % family if family else 'g8_train_step.npz'
+    np.savez_compressed(os.path.join(HERE, out_name), **g8)
     print('losses', g8['losses'], 'acc', g8['accuracy'])
     print('near-zero PReLU inputs recorded:', sum(len(v) for k, v in kinks.items() if k.endswith('.idx')))
-    print('g8_train_step.npz', os.path.getsize(os.path.join(HERE, 'g8_train_step.npz')), 'B')
+    print(out_name, os.path.getsize(os.path.join(HERE, out_name)), 'B')
 
     # ---- the oracle against the reference, right here -------------------------------------
     import ffr_oracle_train as OT
-    sd_e = synth.synth_state_dict(spec_e, seed=0)
-    sd_r = synth.synth_state_dict(spec_r, seed=0)
+    if family:
+        sd_e, sd_r = synth.stress_state_dicts(family, spec_e, spec_r, HERE)
+    else:
+        sd_e, sd_r = synth.synth_state_dict(spec_e, seed=0), synth.synth_state_dict(spec_r, seed=0)
     opt = OT.new_adam_state(sd_r)
     res = OT.train_step(sd_e, sd_r, opt, non, ocl, label, lr=LR)
     print('oracle losses', res['losses'])
@@ -145,4 +155,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -13,6 +13,7 @@ import ffrnet_amd
 from ffrnet_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch_losses as TL  # noqa: E402
@@ -156,13 +157,16 @@ def train_case(specs):
     return build_train_case(specs)
 
 
-def build_train_case(specs, smooth=False):
-    """The G8 scenario (4 clean + 4 occluded images, synthetic weights) through the ORACLE with autograd:
-    outputs, gradients wrt the seven outputs of both RecNet calls, parameter gradients (unclipped)."""
+def build_train_case(specs, smooth=False, family=None):
+    """The G8 scenario (4 clean + 4 occluded images, synthetic weights; `family`: the weights of golden G12 instead) through
+    the ORACLE with autograd: outputs, gradients wrt the seven outputs of both RecNet calls, parameter gradients (unclipped)."""
     import ffr_oracle as O
     import ffr_oracle_train as OT
-    sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
-    sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
+    if family:
+        sd_e, sd_r = synth.stress_state_dicts(family, specs['encoder'], specs['recnet'], os.path.join(ROOT, 'tests', 'golden'))
+    else:
+        sd_e = synth.synth_state_dict(specs['encoder'], seed=0)
+        sd_r = synth.synth_state_dict(specs['recnet'], seed=0)
     if smooth:      # PReLU slopes of 1: the network has no kinks, gradients are continuous in every rounding
         for k in sd_r:
             if k.endswith('func.weight'):
@@ -217,13 +221,16 @@ def test_train_forward_matches_oracle_and_golden(engine, train_case, golden_dir)
             assert int(sd_after[k]) == 2
 
 
-def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir):
+@pytest.mark.parametrize('family', [None, 'kaiming'])
+def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir, specs, family):
     """loss.backward() through RecNet (models/trainer.py:179-180): the 76 parameter gradients for the reference's four
     losses (cotangents of the 7-tuple from the oracle's autograd), in BOTH arithmetics -- direct convolutions and the
     DEFAULT (Winograd F(4x4,3x3) forward and data-gradient convolutions) -- with the reference's real PReLU slopes,
     per tensor, against (1) the oracle on the GPU's side of every kink (see "PReLU kinks" above) and (2) golden G8, the
     clipped gradients of the reference's own Trainer, plus exactly the difference the transplanted kinks make."""
-    tc = train_case
+    # family 'kaiming' (golden G12): the weights a training run STARTS from -- RecNet as init_weights(self.recnet, 'kaiming') leaves it
+    # (models/trainer.py:65-66) behind the trained-like encoder of golden G11; feature maps up to 74, unclipped gradients up to 1e2
+    tc = build_train_case(specs, family=family) if family else train_case
     og = tc['out_grads']
     stacked = []
     for i in range(7):
@@ -235,7 +242,7 @@ def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir
         a = a if a is not None else torch.zeros(ref_shape)
         b = b if b is not None else torch.zeros(ref_shape)
         stacked.append(torch.cat([a, b]).cuda())
-    g8 = np.load(os.path.join(golden_dir, 'g8_train_step.npz'))
+    g8 = np.load(os.path.join(golden_dir, 'g12_train_step_%s.npz' % family if family else 'g8_train_step.npz'))
     own, pre, _ = oracle_grads_on_masks(tc['sd_r'], tc['fm'], tc['f_enc'], tc['label'][:4], None, 4)
     for k in tc['keys']:
         assert grad_err(own[k], tc['param_grads'][k]) < 1e-6     # the helper IS build_train_case's computation
@@ -273,9 +280,9 @@ def test_train_backward_matches_oracle_and_golden(engine, train_case, golden_dir
             assert (samples(got) - expect).abs().max().item() / scale < tol, (mode, k)
             asum = d[1] + ref[k].clamp(-1, 1).double().abs().sum().item() - natural[k].clamp(-1, 1).double().abs().sum().item()
             assert abs(got.clamp(-1.0, 1.0).double().abs().sum().item() - asum) <= tol * max(d[1], 1e-3 * got.numel()), (mode, k)
-        print('winograd=%d: %d of 2.1 M PReLU inputs on the other side of zero (all within %.0e of it); they move the '
+        print('%s winograd=%d: %d of 2.1 M PReLU inputs on the other side of zero (all within %.0e of it); they move the '
               'oracle\'s own gradients by up to %.2e; worst GPU gradient error on the same side %.2e (%s)'
-              % (mode, flipped, fwd_tol, moved, worst[1], worst[0]))
+              % (family or 'benign', mode, flipped, fwd_tol, moved, worst[1], worst[0]))
     engine.train_option('winograd', 1)
 
 
