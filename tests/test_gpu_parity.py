@@ -425,9 +425,7 @@ def test_uint8_input_step_full_size(engine):
     B = 256
     img = torch.randint(0, 256, (B, 112, 112, 3), generator=g, dtype=torch.uint8)
     flip = (torch.rand(B // 2, generator=g) < 0.5).repeat_interleave(2).to(torch.uint8)   # one decision per PAIR (dataset.py:76-79)
-    x = img.flip(-1).permute(0, 3, 1, 2).float().div(255)
-    x = (x - 0.5) / 0.5
-    x = torch.where(flip.view(-1, 1, 1, 1).bool(), x.flip(-1), x).contiguous()
+    x = O.preprocess_u8(img, flip)
     f_new_a, f_a = engine.embed(x.cuda())
     f_new_a, f_a = f_new_a.clone(), f_a.clone()
     f_new_b, f_b = engine.embed_u8(img.cuda(), flip.cuda())
@@ -550,9 +548,7 @@ def test_uint8_input_step_is_bit_identical(engine):
     g = torch.Generator().manual_seed(77)
     img = torch.randint(0, 256, (6, 112, 112, 3), generator=g, dtype=torch.uint8)      # HWC RGB as PIL gives
     flip = torch.tensor([0, 1, 0, 1, 1, 0], dtype=torch.uint8)
-    x = img.flip(-1).permute(0, 3, 1, 2).float().div(255)                               # BGR, ToTensor
-    x = (x - 0.5) / 0.5                                                                 # Normalize
-    x = torch.where(flip.view(-1, 1, 1, 1).bool(), x.flip(-1), x).contiguous()          # tf.hflip
+    x = O.preprocess_u8(img, flip)          # BGR swap, ToTensor, Normalize, tf.hflip: the oracle's restatement of the data pipeline
     f_new_a, f_a = engine.embed(x.cuda())
     f_new_b, f_b = engine.embed_u8(img.cuda(), flip.cuda())
     assert torch.equal(f_new_a, f_new_b) and torch.equal(f_a, f_b)
