@@ -69,8 +69,18 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc16[j][t][r] = 0.f; }
     }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // LOADS == 3: the V fragment in the product's CURRENT memory order ([k half][32 tiles][4 channels]) read for a 16x16x4 B operand:
+    // lane (kq = lane >> 4, t16 = lane & 15) takes channels (2 kq, 2 kq + 1) of tiles t16 and 16 + t16 = two 8-byte loads per step
+    const unsigned lane8 = ((unsigned)(lane >> 5) * 32u + (unsigned)(lane & 15)) * 16u + (unsigned)((lane >> 4) & 1) * 8u;
     auto load = [&](int j, int part, unsigned base, unsigned vbase) {
-        if (VBIG && part == 0) fr[j][part] = ldv(vbase + (unsigned)j * 1024u);
+        if (LOADS == 3 && part == 0) {
+            const __amdgpu_buffer_rsrc_t& r = VBIG ? rv : rs;
+            const unsigned o = VBIG ? vbase + (unsigned)j * 1024u : base + (unsigned)(j * 3) * 1024u;
+            const f32x2 lo = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, lane8, o, 0));
+            const f32x2 hi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + 256u, o, 0));
+            fr[j][0] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else if (VBIG && part == 0) fr[j][part] = ldv(vbase + (unsigned)j * 1024u);
         else fr[j][part] = ldfrag(base + (unsigned)(j * 3 + part) * 1024u);
     };
 #pragma unroll
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void k_chunks(const float* __restrict__ str
                 if constexpr (LOADS != 0) {
 #pragma unroll
                     for (int part = 0; part < 3; ++part) {
-                        const bool here = LOADS == 1 ? g == 1 : g == 1 + 2 * part;
+                        const bool here = LOADS == 1 ? g == 1 : g == 1 + (LOADS == 3 ? 4 : 2) * part;
                         if (here) {
                             if (j == 0) load(8, part, sp, vp);
                             else if (!LAST) load(j - 1, part, sp + 27u * 1024u * 4u, vp + 36864u);
@@ -183,6 +193,8 @@ int main(int argc, char** argv) {
         {"32x32x2  V from a 151 MB region (Inf.Cache)", k_chunks<0, 1, true>, 0, 1},
         {"32x32x2  V from HBM (3 GB, rotating)       ", k_chunks<0, 1, true>, 0, 2},
         {"16x16x4  V from HBM, loads spread          ", k_chunks<1, 2, true>, 1, 2},
+        {"16x16x4  V as 2 x dwordx2 (current order), L2", k_chunks<1, 3>, 1, 0},
+        {"16x16x4  V as 2 x dwordx2, from HBM          ", k_chunks<1, 3, true>, 1, 2},
     };
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("# %s, %d CUs; %d blocks x 256 threads, %d K chunks per block, %.1f s per arm, %s operands\n", prop.gcnArchName,
