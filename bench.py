@@ -776,6 +776,10 @@ def main():
                 # all kernels: PMC bytes per step / SURVEY 8(d)'s algorithmic bytes (56 MB per image + the weights once): the wasted-re-read figure
                 'traffic_ratio_vs_compulsory': ratio_survey,
                 'traffic_compulsory_gb_survey_8d': round(survey_gb, 3),
+                'traffic_compulsory_definition': 'SURVEY 8(d): 14.3 GB x batch / 256 of activations (56 MB per image) + 0.2732 GB of weights per forward; '
+                                                 'valid for THIS workload only (112x112 IR-SE50 + RecNet embed, default options); round 4 and earlier '
+                                                 'printed the per-launch-operand ratio under the key traffic_ratio_vs_compulsory (now '
+                                                 'traffic_ratio_vs_per_launch_operands)',
                 # ... / the sum of every launch's own operands (a V tensor counts for the kernel that writes it AND the one that reads it)
                 'traffic_ratio_vs_per_launch_operands': ratio,
                 'note': 'frac: FLOPs the matrix cores EXECUTED in the fused Winograd launches (2*xi*ceil(T/32)*32*cin_pad*cout_pad per '
